@@ -1,0 +1,210 @@
+/*
+ * promptir_hip.h — C ABI of libpromptir_hip.so (gfx950 / MI355X).
+ *
+ * The reference (kongwanbianjinyu/PromptIR) has no FFI: its operator surface is
+ * torch.nn.Module (net/model.py) and every op is an ATen dispatch.  This header
+ * is the boundary we place UNDER that module surface: one entry point per
+ * ATen op (or fused group of ops) the reference's hot path issues.  Each
+ * declaration cites the reference lines whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - all tensors are fp32, device pointers, NCHW; a "plane" is H*W contiguous floats
+ *  - `*_bs` arguments are batch strides in ELEMENTS, so producers can write into /
+ *    consumers can read from channel slices of a larger (concat / qkv) buffer
+ *  - no allocation, no synchronisation inside; work is enqueued on `stream`
+ *    (a hipStream_t passed as void*); workspaces are passed in by the caller
+ *  - return value: 0 on success, negative on bad arguments (PIR_E*), a positive
+ *    hipError_t if a launch failed.  Never aborts.
+ */
+#ifndef PROMPTIR_HIP_H
+#define PROMPTIR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIR_OK 0
+#define PIR_EINVAL (-22)
+#define PIR_ENOMEM (-12) /* workspace too small */
+
+typedef void* pir_stream_t;
+
+/* library identity: returns the ABI version (bumped on any signature change) */
+int pir_abi_version(void);
+/* name of the code-object architecture the kernels were built for ("gfx950") */
+const char* pir_arch(void);
+
+/* ------------------------------------------------------------------ GEMM core
+ * Batched  Y[o][m][n] = sum_k A[o](m,k) * X[o][k][n]  (+ rowscale[o][m] * R[o][m][n])
+ *   o = o1*O2 + o2 (two-level batch so that (batch, head) slices of a qkv buffer
+ *   can be addressed without copies); A(m,k) = A[m*a_sm + k*a_sk].
+ * Replaces every 1x1 nn.Conv2d of the path — Attention.qkv / project_out
+ * (net/model.py:111,113,120,137), FeedForward.project_in / project_out (:88,92,95,98),
+ * the reduce_* channel mixers (:294,296,303,305,313) — their input gradients
+ * (A = W^T), `attn @ v` (:133) and the dq/dk/dv products of its backward.
+ * rowscale==NULL means 1; R==NULL means no residual (TransformerBlock adds, :193-194).
+ */
+typedef struct {
+  const float* A; long a_s1, a_s2; long a_sm, a_sk;
+  const float* X; long x_s1, x_s2; long ldx;
+  float* Y; long y_s1, y_s2; long ldy;
+  const float* R; long r_s1, r_s2; long ldr;
+  const float* rowscale; long rs_s1, rs_s2;
+  int M, K, N;
+  int O1, O2;
+} pir_gemm_nn_t;
+int pir_gemm_nn(const pir_gemm_nn_t* args, pir_stream_t stream);
+
+/* Dense 3x3 convolution, stride 1, zero pad 1, no bias, as 9 shifted GEMMs:
+ *   Y[b][m][h][w] = sum_{k,dh,dw} Wt[(dh+1)*3+(dw+1)](m,k) * X[b][k][h+dh][w+dw]
+ * A(tap,m,k) = A[tap*a_st + m*a_sm + k*a_sk].  With the natural weight layout
+ * [M][K][3][3]: a_st=1, a_sm=K*9, a_sk=9.  Input gradient: swap m/k strides and pass
+ * flip=1 (tap -> 8-tap).  Replaces OverlapPatchEmbed.proj (net/model.py:206), Downsample /
+ * Upsample body[0] (:164,174), PromptGenBlock.conv3x3 (:223), PromptIR.output (:320).
+ * R (optional) is added to the result (the global residual `+ inp_img`, :377).
+ */
+int pir_conv3x3(const float* A, long a_st, long a_sm, long a_sk, int flip,
+                const float* X, long x_bs, float* Y, long y_bs,
+                const float* R, long r_bs,
+                int B, int M, int K, int H, int W, pir_stream_t stream);
+
+/* G[o][i][j] = sum_{r<BR} sum_n X[o,r][i][n] * Y[o,r][j][n]   (contraction over pixels)
+ *   operand offset = o1*s1 + o2*s2 + r*sr, rows at stride ld.
+ * Split-K over n and r: partial sums go to `ws` and are reduced deterministically by a
+ * second kernel (no atomics).  Replaces `q @ k.transpose(-2,-1)` (net/model.py:130) and
+ * every weight gradient of a 1x1 conv (dW = dY X^T, summed over batch and pixels) and
+ * the dA = dOut V^T product of the attention backward.
+ * Optional 3x3 tap shift on the Y operand (dh,dw with image H,W; n = h*W+w) gives the
+ * dense-3x3 weight gradient: G written with element stride g_sj / row stride g_si.
+ * ws must hold pir_gemm_nt_ws_floats(...) floats.
+ */
+typedef struct {
+  const float* X; long x_s1, x_s2, x_sr; long ldx;
+  const float* Y; long y_s1, y_s2, y_sr; long ldy;
+  float* G; long g_so, g_si, g_sj;
+  int M1, M2, N;
+  int O1, O2, BR;
+  int shift_dh, shift_dw, H, W; /* H==0: no shift */
+  float* ws; size_t ws_floats;
+  float alpha; /* result scale */
+  int accumulate; /* G += result instead of G = result */
+} pir_gemm_nt_t;
+size_t pir_gemm_nt_ws_floats(int M1, int M2, int N, int O, int BR);
+int pir_gemm_nt(const pir_gemm_nt_t* args, pir_stream_t stream);
+
+/* ------------------------------------------------------------------ LayerNorm over channels
+ * net/model.py:47-76 (WithBias, :60-63) and :27-41 (BiasFree, :39-41), applied per pixel over
+ * the channel axis of an NCHW tensor (to_3d / to_4d, :21-25).  eps = 1e-5 inside the sqrt,
+ * biased variance.  bias==NULL selects BiasFree (no mean subtraction in the numerator).
+ * mean / rstd ([B][HW]) are saved for the backward.
+ */
+int pir_layernorm_fwd(const float* x, long x_bs, const float* weight, const float* bias,
+                      float* y, long y_bs, float* mean, float* rstd,
+                      int B, int C, int HW, pir_stream_t stream);
+/* dx; dweight/dbias partial sums are written to ws ([nblk][2][C]) and reduced into dweight/dbias. */
+size_t pir_layernorm_bwd_ws_floats(int B, int C, int HW);
+int pir_layernorm_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* weight,
+                      int with_bias, const float* mean, const float* rstd,
+                      float* dx, long dx_bs, float* dweight, float* dbias,
+                      float* ws, size_t ws_floats, int B, int C, int HW, pir_stream_t stream);
+
+/* ------------------------------------------------------------------ depthwise 3x3 stencil
+ * nn.Conv2d(C, C, 3, padding=1, groups=C, bias=False): Attention.qkv_dwconv
+ * (net/model.py:112,120) and FeedForward.dwconv (:90,96).  w is [C][3][3].
+ * flip=1 correlates with the 180-degree rotated taps (= input gradient).
+ */
+int pir_dwconv3x3(const float* x, long x_bs, const float* w, int flip, float* y, long y_bs,
+                  int B, int C, int H, int W, pir_stream_t stream);
+/* Fused GDFN tail: t = dwconv(x) on 2*hid channels; g = gelu_erf(t[:hid]) * t[hid:]
+ * (net/model.py:96-97).  Writes g ([B][hid][H][W]). */
+int pir_dwconv3x3_gate(const float* x, long x_bs, const float* w, float* g, long g_bs,
+                       int B, int hid, int H, int W, pir_stream_t stream);
+/* Backward of the fused tail: recomputes t from x, forms dt from dg, returns
+ * dx = dwconv^T(dt) is NOT fused here: writes dt ([B][2hid][H][W]) for pir_dwconv3x3(flip=1)
+ * and pir_dwconv3x3_wgrad. */
+int pir_dwconv3x3_gate_bwd(const float* x, long x_bs, const float* w, const float* dg, long dg_bs,
+                           float* dt, long dt_bs, int B, int hid, int H, int W, pir_stream_t stream);
+/* dw[c][tap] = sum_{b,h,w} dy[b][c][h][w] * x[b][c][h+dh][w+dw]; partials in ws. */
+size_t pir_dwconv3x3_wgrad_ws_floats(int B, int C, int H, int W);
+int pir_dwconv3x3_wgrad(const float* dy, long dy_bs, const float* x, long x_bs, float* dw,
+                        float* ws, size_t ws_floats, int B, int C, int H, int W, pir_stream_t stream);
+
+/* ------------------------------------------------------------------ MDTA small-matrix stages
+ * Row sums of squares over the pixel axis: out[b][c] = sum_n x[b][c][n]^2 (the squared
+ * L2 norms F.normalize needs, net/model.py:127-128). */
+int pir_row_sumsq(const float* x, long x_bs, float* out, int B, int C, int HW, pir_stream_t stream);
+/* attn[b][h] = softmax_j( G[b][h][i][j] / (max(|q_i|,1e-12) max(|k_j|,1e-12)) * temperature[h] )
+ * net/model.py:127-131.  sumsq is [B][2C] (q rows then k rows). */
+int pir_mdta_softmax_fwd(const float* gram, const float* sumsq, const float* temperature,
+                         float* attn, int B, int heads, int c, pir_stream_t stream);
+/* Backward through softmax, temperature and the two normalisations.
+ * In: dattn, attn, gram, sumsq, temperature.  Out: dgram ([B][h][c][c], already divided by the
+ * norms), alpha_q / alpha_k ([B][C]) such that
+ *   dq = dgram k + alpha_q * q,  dk = dgram^T q + alpha_k * k,
+ * and dtemp_partial[b][h] (summed over b by pir_reduce_partials).  c <= 256. */
+int pir_mdta_softmax_bwd(const float* dattn, const float* attn, const float* gram, const float* sumsq,
+                         const float* temperature, float* dgram,
+                         float* alpha_q, float* alpha_k, float* dtemp_partial,
+                         int B, int heads, int c, pir_stream_t stream);
+
+/* ------------------------------------------------------------------ pixel (un)shuffle
+ * nn.PixelUnshuffle(2) / nn.PixelShuffle(2) (net/model.py:165,175). Each is the other's adjoint.
+ * unshuffle: y[b][c*4+i*2+j][h][w] = x[b][c][2h+i][2w+j]   (x is [B][C][2H][2W], y [B][4C][H][W])
+ * shuffle  : y[b][c][2h+i][2w+j]   = x[b][c*4+i*2+j][h][w] (x is [B][4C][H][W], y [B][C][2H][2W])
+ * C, H, W always describe the LOW-resolution, 4C-channel side. */
+int pir_pixel_unshuffle2(const float* x, long x_bs, float* y, long y_bs, int B, int C, int H, int W,
+                         pir_stream_t stream);
+int pir_pixel_shuffle2(const float* x, long x_bs, float* y, long y_bs, int B, int C, int H, int W,
+                       pir_stream_t stream);
+
+/* ------------------------------------------------------------------ PromptGenBlock (net/model.py:226-235)
+ * emb = mean over pixels (:228) */
+int pir_spatial_mean(const float* x, long x_bs, float* out, int B, int C, int HW, pir_stream_t stream);
+/* mix = softmax(emb @ Wl^T + bl) over the L prompts (:229). Wl [L][C]. */
+int pir_prompt_mix_fwd(const float* emb, const float* Wl, const float* bl, float* mix,
+                       int B, int C, int L, pir_stream_t stream);
+/* out[b][d][y][x] = bilinear_{align_corners=False}( sum_l mix[b][l] * P[l][d] )(y,x) (:230-232) */
+int pir_prompt_resize_fwd(const float* mix, const float* P, float* out, long out_bs,
+                          int B, int L, int D, int S, int H, int W, pir_stream_t stream);
+/* adjoint: dP[l][d][s][t] = sum_b mix[b][l] * resize^T(dout[b][d])(s,t);
+ *          dmix[b][l] = <dout[b], resize(P[l])> .  ws: B*D*S*S floats (+ partials). */
+size_t pir_prompt_resize_bwd_ws_floats(int B, int L, int D, int S, int H, int W);
+int pir_prompt_resize_bwd(const float* dout, long dout_bs, const float* mix, const float* P,
+                          float* dP, float* dmix, float* ws, size_t ws_floats,
+                          int B, int L, int D, int S, int H, int W, pir_stream_t stream);
+/* backward of softmax+linear+mean: given dmix -> dWl [L][C], dbl [L], and writes (or, with
+ * accumulate, adds) demb[b][c]/HW to every pixel of dx[b][c]. */
+int pir_prompt_mix_bwd(const float* dmix, const float* mix, const float* emb, const float* Wl,
+                       float* dWl, float* dbl, float* dx, long dx_bs, int accumulate,
+                       int B, int C, int L, int HW, pir_stream_t stream);
+
+/* ------------------------------------------------------------------ loss, copies, optimiser
+ * nn.L1Loss() (train.py:32,43): loss = mean|a-b|; optional fused grad = sign(a-b)/count * gscale
+ * (grad may be NULL). ws: 1024 floats. */
+int pir_l1_loss(const float* restored, const float* clean, float* loss, float* grad, float gscale,
+                float* ws, long count, pir_stream_t stream);
+/* backward of the same loss with the upstream scalar gradient read from device memory:
+ * grad = sign(restored-clean) * dloss[0] / count */
+int pir_l1_loss_grad(const float* restored, const float* clean, const float* dloss, float* grad,
+                     long count, pir_stream_t stream);
+/* y[b][c][n] = x[b][c][n] (+ y if accumulate) for channel-slice copies (torch.cat, net/model.py:341-370) */
+int pir_copy_planes(const float* x, long x_bs, float* y, long y_bs, int accumulate,
+                    int B, long plane_floats, pir_stream_t stream);
+/* out[i] = a[i] + b[i] */
+int pir_add(const float* a, const float* b, float* out, long count, pir_stream_t stream);
+/* out[j] = alpha * sum_{s<S} parts[s*stride + j] (+ out[j] if accumulate) */
+int pir_reduce_partials(const float* parts, long stride, int S, float alpha, int accumulate,
+                        float* out, long count, pir_stream_t stream);
+/* torch.optim.AdamW step (train.py:53: lr 2e-4, betas .9/.999, eps 1e-8, weight_decay 1e-2),
+ * over a flat parameter / gradient / moment buffer.  `step` is the 1-based step count. */
+int pir_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long count,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, long step,
+                   float grad_scale, pir_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROMPTIR_HIP_H */

@@ -1,0 +1,130 @@
+// Small-matrix stages of MDTA (net/model.py:127-131): the c x c channel-attention map per
+// (image, head).  c <= 176 in PromptIR, so one workgroup owns one map; rows go to waves,
+// columns to lanes, reductions are wave64 shuffles.  These are launch-latency-sized kernels;
+// the heavy lifting (q k^T over pixels, attn @ v) is in gemm.hip.
+#include "pir_common.h"
+
+namespace {
+
+constexpr float NORM_EPS = 1e-12f;  // F.normalize default eps
+
+// attn = softmax_j( gram[i][j] / (nq_i nk_j) * temperature ),  n* = max(sqrt(sumsq), eps)
+__global__ __launch_bounds__(256) void mdta_softmax_fwd_kernel(const float* __restrict__ gram,
+                                                               const float* __restrict__ sumsq,
+                                                               const float* __restrict__ temperature,
+                                                               float* __restrict__ attn, int heads, int c) {
+  const int bh = blockIdx.x, b = bh / heads, h = bh % heads, C = heads * c;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const float* G = gram + (long)bh * c * c;
+  float* A = attn + (long)bh * c * c;
+  const float* sq = sumsq + (long)b * 2 * C + h * c;
+  const float* sk = sq + C;
+  const float t = temperature[h];
+  for (int i = wid; i < c; i += nw) {
+    const float inv_q = 1.f / fmaxf(sqrtf(sq[i]), NORM_EPS);
+    float m = -INFINITY;
+    for (int j = lane; j < c; j += 64) {
+      const float s = G[i * c + j] * inv_q / fmaxf(sqrtf(sk[j]), NORM_EPS) * t;
+      m = fmaxf(m, s);
+    }
+    m = pir_wave_max(m);
+    float sum = 0.f;
+    for (int j = lane; j < c; j += 64) {
+      const float s = G[i * c + j] * inv_q / fmaxf(sqrtf(sk[j]), NORM_EPS) * t;
+      sum += expf(s - m);
+    }
+    sum = pir_wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int j = lane; j < c; j += 64) {
+      const float s = G[i * c + j] * inv_q / fmaxf(sqrtf(sk[j]), NORM_EPS) * t;
+      A[i * c + j] = expf(s - m) * inv;
+    }
+  }
+}
+
+// Backward through softmax, temperature and both L2 normalisations (see include/promptir_hip.h).
+__global__ __launch_bounds__(256) void mdta_softmax_bwd_kernel(
+    const float* __restrict__ dattn, const float* __restrict__ attn, const float* __restrict__ gram,
+    const float* __restrict__ sumsq, const float* __restrict__ temperature, float* __restrict__ dgram,
+    float* __restrict__ alpha_q, float* __restrict__ alpha_k, float* __restrict__ dtemp_partial, int heads, int c) {
+  constexpr int MAXJ = 4;  // c <= 256 columns per lane-strided pass
+  __shared__ float colred[4][256];
+  __shared__ float red[16];
+  const int bh = blockIdx.x, b = bh / heads, h = bh % heads, C = heads * c;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const float* G = gram + (long)bh * c * c;
+  const float* A = attn + (long)bh * c * c;
+  const float* dA = dattn + (long)bh * c * c;
+  float* dG = dgram + (long)bh * c * c;
+  const float* sq = sumsq + (long)b * 2 * C + h * c;
+  const float* sk = sq + C;
+  const float t = temperature[h];
+
+  float inv_k[MAXJ], col[MAXJ];
+#pragma unroll
+  for (int u = 0; u < MAXJ; ++u) {
+    const int j = lane + 64 * u;
+    inv_k[u] = j < c ? 1.f / fmaxf(sqrtf(sk[j]), NORM_EPS) : 0.f;
+    col[u] = 0.f;
+  }
+  float dt_acc = 0.f;
+  for (int i = wid; i < c; i += nw) {
+    const float nq = fmaxf(sqrtf(sq[i]), NORM_EPS);
+    const float inv_q = 1.f / nq;
+    float dot = 0.f;
+#pragma unroll
+    for (int u = 0; u < MAXJ; ++u) {
+      const int j = lane + 64 * u;
+      if (j < c) dot += dA[i * c + j] * A[i * c + j];
+    }
+    dot = pir_wave_sum(dot);
+    float rowterm = 0.f;
+#pragma unroll
+    for (int u = 0; u < MAXJ; ++u) {
+      const int j = lane + 64 * u;
+      if (j < c) {
+        const float dS = A[i * c + j] * (dA[i * c + j] - dot);
+        const float R = G[i * c + j] * inv_q * inv_k[u];
+        dt_acc += dS * R;
+        const float dR = t * dS;
+        dG[i * c + j] = dR * inv_q * inv_k[u];
+        rowterm += dR * R;
+        col[u] += dR * R;
+      }
+    }
+    rowterm = pir_wave_sum(rowterm);
+    if (lane == 0) alpha_q[(long)b * C + h * c + i] = sqrtf(sq[i]) > NORM_EPS ? -rowterm * inv_q * inv_q : 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < MAXJ; ++u) colred[wid][lane + 64 * u] = col[u];
+  __syncthreads();
+  for (int j = threadIdx.x; j < c; j += blockDim.x) {
+    float s = 0.f;
+    for (int w = 0; w < nw; ++w) s += colred[w][j];
+    const float nk = fmaxf(sqrtf(sk[j]), NORM_EPS);
+    alpha_k[(long)b * C + h * c + j] = sqrtf(sk[j]) > NORM_EPS ? -s / (nk * nk) : 0.f;
+  }
+  const float dt = pir_block_sum(dt_acc, red);
+  if (threadIdx.x == 0) dtemp_partial[bh] = dt;
+}
+
+}  // namespace
+
+extern "C" int pir_mdta_softmax_fwd(const float* gram, const float* sumsq, const float* temperature,
+                                    float* attn, int B, int heads, int c, pir_stream_t stream) {
+  PIR_CHECK_ARG(gram && sumsq && temperature && attn && B > 0 && heads > 0 && c > 0);
+  hipLaunchKernelGGL(mdta_softmax_fwd_kernel, dim3((unsigned)(B * heads)), dim3(256), 0, (hipStream_t)stream,
+                     gram, sumsq, temperature, attn, heads, c);
+  return pir_launch_status();
+}
+
+extern "C" int pir_mdta_softmax_bwd(const float* dattn, const float* attn, const float* gram, const float* sumsq,
+                                    const float* temperature, float* dgram,
+                                    float* alpha_q, float* alpha_k, float* dtemp_partial,
+                                    int B, int heads, int c, pir_stream_t stream) {
+  PIR_CHECK_ARG(dattn && attn && gram && sumsq && temperature && dgram && alpha_q && alpha_k && dtemp_partial);
+  PIR_CHECK_ARG(B > 0 && heads > 0 && c > 0 && c <= 256);
+  hipLaunchKernelGGL(mdta_softmax_bwd_kernel, dim3((unsigned)(B * heads)), dim3(256), 0, (hipStream_t)stream,
+                     dattn, attn, gram, sumsq, temperature, dgram, alpha_q, alpha_k, dtemp_partial, heads, c);
+  return pir_launch_status();
+}

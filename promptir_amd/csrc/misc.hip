@@ -1,0 +1,161 @@
+// Loss, plane copies, partial-sum reduction and the AdamW step (gfx950), all HBM-bound streams.
+#include "pir_common.h"
+#include <math.h>
+
+namespace {
+
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         float* __restrict__ grad, float gval, float* __restrict__ ws,
+                                                         long count) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+    const float d = a[i] - b[i];
+    s += fabsf(d);
+    if (grad) grad[i] = d > 0.f ? gval : (d < 0.f ? -gval : 0.f);
+  }
+  const float t = pir_block_sum(s, red);
+  if (threadIdx.x == 0) ws[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void l1_final_kernel(const float* __restrict__ ws, int n, float inv_count,
+                                                       float* __restrict__ loss) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += ws[i];
+  const float t = pir_block_sum(s, red);
+  if (threadIdx.x == 0) loss[0] = t * inv_count;
+}
+
+// grad = sign(a-b) * (*dloss) / count : backward of the mean-absolute-error with the upstream
+// gradient read from device memory (no host sync).
+__global__ __launch_bounds__(256) void l1_grad_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      const float* __restrict__ dloss, float inv_count,
+                                                      float* __restrict__ grad, long count) {
+  const float gval = dloss[0] * inv_count;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+    const float d = a[i] - b[i];
+    grad[i] = d > 0.f ? gval : (d < 0.f ? -gval : 0.f);
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void copy_planes_kernel(const float* __restrict__ x, long x_bs, float* __restrict__ y,
+                                                          long y_bs, int accumulate, int B, long n) {
+  const long per = n / VEC, total = (long)B * per;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long b = e / per, i = (e % per) * VEC;
+    if (VEC == 4) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(x + b * x_bs + i);
+      f32x4* d = reinterpret_cast<f32x4*>(y + b * y_bs + i);
+      if (accumulate) v += *d;
+      *d = v;
+    } else {
+      float v = x[b * x_bs + i];
+      if (accumulate) v += y[b * y_bs + i];
+      y[b * y_bs + i] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out, long count) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+    out[i] = a[i] + b[i];
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ parts, long stride, int S,
+                                                              float alpha, int accumulate, float* __restrict__ out,
+                                                              long count) {
+  for (long j = blockIdx.x * (long)blockDim.x + threadIdx.x; j < count; j += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += parts[k * stride + j];
+    s *= alpha;
+    out[j] = accumulate ? out[j] + s : s;
+  }
+}
+
+// torch.optim.AdamW single-tensor update, same operation order:
+//   p *= 1 - lr*wd; m = lerp(m, g, 1-b1); v = b2*v + (1-b2) g^2;
+//   p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, long count,
+                                                    float decay, float beta1, float beta2, float eps,
+                                                    float step_size, float inv_bc2_sqrt, float grad_scale) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * grad_scale;
+    float pi = p[i] * decay;
+    float mi = m[i];
+    mi = mi + (1.f - beta1) * (gi - mi);
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+    pi -= step_size * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+
+inline int grid_for(long total, int cap = 4096) { long g = pir_cdiv(total, 256); if (g < 1) g = 1; return (int)(g < cap ? g : cap); }
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int pir_abi_version(void) { return 1; }
+extern "C" const char* pir_arch(void) { return "gfx950"; }
+
+extern "C" int pir_l1_loss(const float* restored, const float* clean, float* loss, float* grad, float gscale,
+                           float* ws, long count, pir_stream_t stream) {
+  PIR_CHECK_ARG(restored && clean && loss && ws && count > 0);
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = grid_for(count, 1024);
+  hipLaunchKernelGGL(l1_partial_kernel, dim3(blocks), dim3(256), 0, s, restored, clean, grad, gscale / (float)count, ws, count);
+  int st = pir_launch_status();
+  if (st) return st;
+  hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, s, ws, blocks, 1.f / (float)count, loss);
+  return pir_launch_status();
+}
+
+extern "C" int pir_l1_loss_grad(const float* restored, const float* clean, const float* dloss, float* grad,
+                                long count, pir_stream_t stream) {
+  PIR_CHECK_ARG(restored && clean && dloss && grad && count > 0);
+  hipLaunchKernelGGL(l1_grad_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream,
+                     restored, clean, dloss, 1.f / (float)count, grad, count);
+  return pir_launch_status();
+}
+
+extern "C" int pir_copy_planes(const float* x, long x_bs, float* y, long y_bs, int accumulate,
+                               int B, long plane_floats, pir_stream_t stream) {
+  PIR_CHECK_ARG(x && y && B > 0 && plane_floats > 0);
+  const bool v4 = plane_floats % 4 == 0 && x_bs % 4 == 0 && y_bs % 4 == 0 && al16(x) && al16(y);
+  hipStream_t s = (hipStream_t)stream;
+  if (v4) hipLaunchKernelGGL((copy_planes_kernel<4>), dim3(grid_for((long)B * plane_floats / 4)), dim3(256), 0, s, x, x_bs, y, y_bs, accumulate, B, plane_floats);
+  else hipLaunchKernelGGL((copy_planes_kernel<1>), dim3(grid_for((long)B * plane_floats)), dim3(256), 0, s, x, x_bs, y, y_bs, accumulate, B, plane_floats);
+  return pir_launch_status();
+}
+
+extern "C" int pir_add(const float* a, const float* b, float* out, long count, pir_stream_t stream) {
+  PIR_CHECK_ARG(a && b && out && count > 0);
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, a, b, out, count);
+  return pir_launch_status();
+}
+
+extern "C" int pir_reduce_partials(const float* parts, long stride, int S, float alpha, int accumulate,
+                                   float* out, long count, pir_stream_t stream) {
+  PIR_CHECK_ARG(parts && out && S > 0 && count > 0);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream,
+                     parts, stride, S, alpha, accumulate, out, count);
+  return pir_launch_status();
+}
+
+extern "C" int pir_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long count,
+                              float lr, float beta1, float beta2, float eps, float weight_decay, long step,
+                              float grad_scale, pir_stream_t stream) {
+  PIR_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && count > 0 && step > 0);
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  const float decay = 1.f - lr * weight_decay;
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(count, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     param, grad, exp_avg, exp_avg_sq, count, decay, beta1, beta2, eps, step_size, inv_bc2_sqrt, grad_scale);
+  return pir_launch_status();
+}

@@ -1,0 +1,244 @@
+// Channel LayerNorm and the pixel-axis reductions of the PromptIR path (gfx950), HBM-bound.
+//
+// NCHW keeps the normalised axis (C) OUTERMOST, so the reference's to_3d/to_4d permutes
+// (net/model.py:21-25) are never materialised: a workgroup owns 64 consecutive pixels (one
+// 256-byte coalesced row segment per channel) and its 4 waves split the channels; per-pixel
+// statistics are combined through LDS.  For C <= 256 the wave's channel slice stays in
+// registers between the statistics and the normalisation, so x is read from HBM once.
+#include "pir_common.h"
+
+namespace {
+
+constexpr int LN_PIX = 64;    // pixels per workgroup (one per lane)
+constexpr int LN_WAVES = 4;
+constexpr float LN_EPS = 1e-5f;
+
+// NREG: compile-time bound on channels per wave kept in registers (0 = re-read from memory/L2)
+template <int NREG>
+__global__ __launch_bounds__(LN_PIX* LN_WAVES) void ln_fwd_kernel(
+    const float* __restrict__ x, long x_bs, const float* __restrict__ weight, const float* __restrict__ bias,
+    float* __restrict__ y, long y_bs, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+    int C, int HW, int tiles) {
+  __shared__ float red[LN_WAVES][LN_PIX];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int b = blockIdx.x / tiles, p = (blockIdx.x % tiles) * LN_PIX + lane;
+  const bool ok = p < HW;
+  const float* xb = x + b * x_bs + p;
+  float v[NREG > 0 ? NREG : 1];
+
+  float s = 0.f;
+  if (NREG > 0) {
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+      const int c = wid + i * LN_WAVES;
+      v[i] = (ok && c < C) ? xb[(long)c * HW] : 0.f;
+      s += v[i];
+    }
+  } else {
+    for (int c = wid; c < C; c += LN_WAVES) s += ok ? xb[(long)c * HW] : 0.f;
+  }
+  red[wid][lane] = s;
+  __syncthreads();
+  const float mu = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+  __syncthreads();
+
+  float ss = 0.f;
+  if (NREG > 0) {
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+      const int c = wid + i * LN_WAVES;
+      const float d = (c < C) ? v[i] - mu : 0.f;
+      ss += d * d;
+    }
+  } else {
+    for (int c = wid; c < C; c += LN_WAVES) {
+      const float d = ok ? xb[(long)c * HW] - mu : 0.f;
+      ss += d * d;
+    }
+  }
+  red[wid][lane] = ss;
+  __syncthreads();
+  const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+  const float rstd = 1.f / sqrtf(var + LN_EPS);
+  if (wid == 0 && ok) {
+    mean_out[(long)b * HW + p] = mu;
+    rstd_out[(long)b * HW + p] = rstd;
+  }
+  if (!ok) return;
+  float* yb = y + b * y_bs + p;
+  const float shift = bias ? mu : 0.f;  // BiasFree keeps the un-centred numerator (net/model.py:41)
+  if (NREG > 0) {
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+      const int c = wid + i * LN_WAVES;
+      if (c < C) yb[(long)c * HW] = (v[i] - shift) * rstd * weight[c] + (bias ? bias[c] : 0.f);
+    }
+  } else {
+    for (int c = wid; c < C; c += LN_WAVES)
+      yb[(long)c * HW] = (xb[(long)c * HW] - shift) * rstd * weight[c] + (bias ? bias[c] : 0.f);
+  }
+}
+
+// dx for both variants.  g = dy*w.
+//  WithBias : dx = rstd * (g - mean_c(g) - xhat * mean_c(g*xhat)),           xhat = (x-mu)*rstd
+//  BiasFree : y = x*rstd*w  ->  dx = rstd*g - rstd^3 * (x-mu) * mean_c(g*x)
+__global__ __launch_bounds__(LN_PIX* LN_WAVES) void ln_bwd_dx_kernel(
+    const float* __restrict__ dy, long dy_bs, const float* __restrict__ x, long x_bs,
+    const float* __restrict__ weight, int with_bias, const float* __restrict__ mean, const float* __restrict__ rstd,
+    float* __restrict__ dx, long dx_bs, int C, int HW, int tiles) {
+  __shared__ float red[2][LN_WAVES][LN_PIX];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int b = blockIdx.x / tiles, p = (blockIdx.x % tiles) * LN_PIX + lane;
+  const bool ok = p < HW;
+  const float* xb = x + b * x_bs + p;
+  const float* gb = dy + b * dy_bs + p;
+  const float mu = ok ? mean[(long)b * HW + p] : 0.f;
+  const float rs = ok ? rstd[(long)b * HW + p] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = wid; c < C; c += LN_WAVES) {
+    if (ok) {
+      const float g = gb[(long)c * HW] * weight[c];
+      const float xv = xb[(long)c * HW];
+      s1 += g;
+      s2 += g * (with_bias ? (xv - mu) * rs : xv);
+    }
+  }
+  red[0][wid][lane] = s1;
+  red[1][wid][lane] = s2;
+  __syncthreads();
+  const float m1 = (red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]) / (float)C;
+  const float m2 = (red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]) / (float)C;
+  if (!ok) return;
+  float* db = dx + b * dx_bs + p;
+  for (int c = wid; c < C; c += LN_WAVES) {
+    const float g = gb[(long)c * HW] * weight[c];
+    const float xv = xb[(long)c * HW];
+    float r;
+    if (with_bias) r = rs * (g - m1 - (xv - mu) * rs * m2);
+    else r = rs * g - rs * rs * rs * (xv - mu) * m2;
+    db[(long)c * HW] = r;
+  }
+}
+
+// dweight[c] = sum_{b,p} dy * xhat ; dbias[c] = sum dy.  grid (C, S); partials [S][2][C].
+__global__ __launch_bounds__(256) void ln_bwd_param_kernel(
+    const float* __restrict__ dy, long dy_bs, const float* __restrict__ x, long x_bs, int with_bias,
+    const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ ws, int B, int C, int HW) {
+  __shared__ float red[16];
+  const int c = blockIdx.x, S = gridDim.y, sidx = blockIdx.y;
+  const long total = (long)B * HW;
+  const long per = (total + S - 1) / S;
+  const long e0 = sidx * per, e1 = (e0 + per < total) ? e0 + per : total;
+  float sw = 0.f, sb = 0.f;
+  for (long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+    const long b = e / HW, p = e % HW;
+    const float g = dy[b * dy_bs + (long)c * HW + p];
+    const float xv = x[b * x_bs + (long)c * HW + p];
+    const float rs = rstd[e];
+    sw += g * (with_bias ? (xv - mean[e]) * rs : xv * rs);
+    sb += g;
+  }
+  const float tw = pir_block_sum(sw, red);
+  const float tb = pir_block_sum(sb, red);
+  if (threadIdx.x == 0) {
+    ws[((long)sidx * 2 + 0) * C + c] = tw;
+    ws[((long)sidx * 2 + 1) * C + c] = tb;
+  }
+}
+
+// out[row] = reduce over n of f(x[row][n]); one wave per row when N is small, a block otherwise.
+template <bool SQUARE>
+__global__ __launch_bounds__(256) void row_reduce_kernel(const float* __restrict__ x, long x_bs, float* __restrict__ out,
+                                                         int C, int HW, float scale) {
+  __shared__ float red[16];
+  const int b = blockIdx.x / C, c = blockIdx.x % C;
+  const float* row = x + b * x_bs + (long)c * HW;
+  float s = 0.f;
+  if ((HW & 3) == 0 && (reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(row);
+    for (int i = threadIdx.x; i < HW / 4; i += blockDim.x) {
+      const f32x4 v = r4[i];
+      s += SQUARE ? (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]) : (v[0] + v[1]) + (v[2] + v[3]);
+    }
+  } else {
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) s += SQUARE ? row[i] * row[i] : row[i];
+  }
+  const float t = pir_block_sum(s, red);
+  if (threadIdx.x == 0) out[(long)b * C + c] = t * scale;
+}
+
+int ln_threads_for(int HW) { return HW >= 4096 ? 256 : (HW >= 1024 ? 128 : 64); }
+
+}  // namespace
+
+extern "C" int pir_reduce_partials(const float* parts, long stride, int S, float alpha, int accumulate,
+                                   float* out, long count, pir_stream_t stream);
+
+extern "C" int pir_layernorm_fwd(const float* x, long x_bs, const float* weight, const float* bias,
+                                 float* y, long y_bs, float* mean, float* rstd,
+                                 int B, int C, int HW, pir_stream_t stream) {
+  PIR_CHECK_ARG(x && weight && y && mean && rstd && B > 0 && C > 0 && HW > 0);
+  const int tiles = (int)pir_cdiv(HW, LN_PIX);
+  dim3 grid((unsigned)((long)B * tiles)), block(LN_PIX * LN_WAVES);
+  hipStream_t s = (hipStream_t)stream;
+#define PIR_LN(NR) hipLaunchKernelGGL((ln_fwd_kernel<NR>), grid, block, 0, s, x, x_bs, weight, bias, y, y_bs, mean, rstd, C, HW, tiles)
+  if (C <= 64) PIR_LN(16);
+  else if (C <= 128) PIR_LN(32);
+  else if (C <= 256) PIR_LN(64);
+  else PIR_LN(0);
+#undef PIR_LN
+  return pir_launch_status();
+}
+
+static int ln_param_splits(int B, int C, int HW) {
+  const long total = (long)B * HW;
+  long s = pir_cdiv(4L * PIR_NUM_CU, C);
+  const long max_s = pir_cdiv(total, 2048);
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+extern "C" size_t pir_layernorm_bwd_ws_floats(int B, int C, int HW) {
+  if (B <= 0 || C <= 0 || HW <= 0) return 0;
+  return (size_t)ln_param_splits(B, C, HW) * 2 * C;
+}
+
+extern "C" int pir_layernorm_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* weight,
+                                 int with_bias, const float* mean, const float* rstd,
+                                 float* dx, long dx_bs, float* dweight, float* dbias,
+                                 float* ws, size_t ws_floats, int B, int C, int HW, pir_stream_t stream) {
+  PIR_CHECK_ARG(dy && x && weight && mean && rstd && dx && dweight && ws && B > 0 && C > 0 && HW > 0);
+  PIR_CHECK_ARG(!with_bias || dbias);
+  const int S = ln_param_splits(B, C, HW);
+  if ((size_t)S * 2 * C > ws_floats) return PIR_ENOMEM;
+  hipStream_t s = (hipStream_t)stream;
+  const int tiles = (int)pir_cdiv(HW, LN_PIX);
+  hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3((unsigned)((long)B * tiles)), dim3(LN_PIX * LN_WAVES), 0, s,
+                     dy, dy_bs, x, x_bs, weight, with_bias, mean, rstd, dx, dx_bs, C, HW, tiles);
+  int st = pir_launch_status();
+  if (st) return st;
+  hipLaunchKernelGGL(ln_bwd_param_kernel, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s,
+                     dy, dy_bs, x, x_bs, with_bias, mean, rstd, ws, B, C, HW);
+  st = pir_launch_status();
+  if (st) return st;
+  // partials are [S][2][C]: reduce the two halves separately
+  st = pir_reduce_partials(ws, 2L * C, S, 1.f, 0, dweight, C, stream);
+  if (st) return st;
+  if (with_bias) st = pir_reduce_partials(ws + C, 2L * C, S, 1.f, 0, dbias, C, stream);
+  return st;
+}
+
+extern "C" int pir_row_sumsq(const float* x, long x_bs, float* out, int B, int C, int HW, pir_stream_t stream) {
+  PIR_CHECK_ARG(x && out && B > 0 && C > 0 && HW > 0);
+  hipLaunchKernelGGL((row_reduce_kernel<true>), dim3((unsigned)((long)B * C)), dim3(ln_threads_for(HW)), 0,
+                     (hipStream_t)stream, x, x_bs, out, C, HW, 1.f);
+  return pir_launch_status();
+}
+
+extern "C" int pir_spatial_mean(const float* x, long x_bs, float* out, int B, int C, int HW, pir_stream_t stream) {
+  PIR_CHECK_ARG(x && out && B > 0 && C > 0 && HW > 0);
+  hipLaunchKernelGGL((row_reduce_kernel<false>), dim3((unsigned)((long)B * C)), dim3(ln_threads_for(HW)), 0,
+                     (hipStream_t)stream, x, x_bs, out, C, HW, 1.f / (float)HW);
+  return pir_launch_status();
+}

@@ -1,0 +1,337 @@
+"""PromptIR nn.Module surface over the HIP kernels.
+
+Mirrors the reference's module tree (class names, constructor arguments, attribute
+names and therefore every state_dict key / shape of /root/reference/net/model.py) so
+that train / test / demo drivers and Lightning `net.*` checkpoints interchange, while
+every forward/backward op dispatches to libpromptir_hip.so through `promptir_amd.ops`.
+
+The module only runs on ROCm tensors.  A CPU tensor raises (no eager fallback); the CPU
+reference lives in `oracle/` and is test infrastructure.
+"""
+from __future__ import annotations
+
+import math
+import numbers
+from typing import Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _check_channels(x: torch.Tensor, expected: int, who: str) -> None:
+    if x.dim() != 4 or x.shape[1] != expected:
+        raise RuntimeError(f"{who}: expected input[B, {expected}, H, W] but got {list(x.shape)}")
+
+
+class _ConvParams(nn.Module):
+    """Bias-free convolution weight holder with nn.Conv2d's parameter name, shape and default init."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int, groups: int = 1, bias: bool = False):
+        super().__init__()
+        if bias:
+            raise NotImplementedError("bias=True is not built: every caller of the reference uses bias=False "
+                                      "(net/model.py:253, train.py:31)")
+        self.in_channels, self.out_channels, self.kernel_size, self.groups = in_channels, out_channels, kernel_size, groups
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, kernel_size, kernel_size))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))  # nn.Conv2d.reset_parameters
+
+
+class Conv1x1(_ConvParams):
+    """nn.Conv2d(cin, cout, kernel_size=1, bias=False) -> fp32 MFMA GEMM (pir_gemm_nn)."""
+
+    def __init__(self, in_channels, out_channels, bias=False):
+        super().__init__(in_channels, out_channels, 1, 1, bias)
+
+    def forward(self, x, residual: Optional[torch.Tensor] = None):
+        _check_channels(x, self.in_channels, "Conv1x1")
+        return ops.Conv1x1Fn.apply(x, self.weight, residual)
+
+
+class Conv3x3(_ConvParams):
+    """nn.Conv2d(cin, cout, 3, stride=1, padding=1, bias=False) -> 9 shifted MFMA GEMMs (pir_conv3x3)."""
+
+    def __init__(self, in_channels, out_channels, bias=False):
+        super().__init__(in_channels, out_channels, 3, 1, bias)
+
+    def forward(self, x, residual: Optional[torch.Tensor] = None):
+        _check_channels(x, self.in_channels, "Conv3x3")
+        return ops.Conv3x3Fn.apply(x, self.weight, residual)
+
+
+class DepthwiseConv3x3(_ConvParams):
+    """nn.Conv2d(C, C, 3, padding=1, groups=C, bias=False) -> LDS-tiled stencil (pir_dwconv3x3)."""
+
+    def __init__(self, channels, bias=False):
+        super().__init__(channels, channels, 3, channels, bias)
+
+    def forward(self, x):
+        _check_channels(x, self.in_channels, "DepthwiseConv3x3")
+        return ops.DwConvFn.apply(x, self.weight)
+
+
+class PixelUnshuffle2(nn.Module):
+    def forward(self, x):
+        return ops.PixelUnshuffleFn.apply(x)
+
+
+class PixelShuffle2(nn.Module):
+    def forward(self, x):
+        return ops.PixelShuffleFn.apply(x)
+
+
+##########################################################################
+## Layer Norm (reference net/model.py:27-76)
+class BiasFree_LayerNorm(nn.Module):
+    def __init__(self, normalized_shape):
+        super().__init__()
+        if isinstance(normalized_shape, numbers.Integral):
+            normalized_shape = (normalized_shape,)
+        assert len(normalized_shape) == 1
+        self.weight = nn.Parameter(torch.ones(normalized_shape))
+        self.normalized_shape = torch.Size(normalized_shape)
+
+    def forward(self, x):  # x: NCHW (the to_3d/to_4d permutes are never materialised)
+        return ops.LayerNormFn.apply(x, self.weight, None)
+
+
+class WithBias_LayerNorm(nn.Module):
+    def __init__(self, normalized_shape):
+        super().__init__()
+        if isinstance(normalized_shape, numbers.Integral):
+            normalized_shape = (normalized_shape,)
+        assert len(normalized_shape) == 1
+        self.weight = nn.Parameter(torch.ones(normalized_shape))
+        self.bias = nn.Parameter(torch.zeros(normalized_shape))
+        self.normalized_shape = torch.Size(normalized_shape)
+
+    def forward(self, x):
+        return ops.LayerNormFn.apply(x, self.weight, self.bias)
+
+
+class LayerNorm(nn.Module):
+    def __init__(self, dim, LayerNorm_type):
+        super().__init__()
+        self.body = BiasFree_LayerNorm(dim) if LayerNorm_type == 'BiasFree' else WithBias_LayerNorm(dim)
+
+    def forward(self, x):
+        _check_channels(x, self.body.normalized_shape[0], "LayerNorm")
+        return self.body(x)
+
+
+##########################################################################
+## Gated-Dconv Feed-Forward Network (reference net/model.py:82-99)
+class FeedForward(nn.Module):
+    def __init__(self, dim, ffn_expansion_factor, bias):
+        super().__init__()
+        hidden_features = int(dim * ffn_expansion_factor)
+        self.project_in = Conv1x1(dim, hidden_features * 2, bias=bias)
+        self.dwconv = DepthwiseConv3x3(hidden_features * 2, bias=bias)
+        self.project_out = Conv1x1(hidden_features, dim, bias=bias)
+
+    def forward(self, x, residual: Optional[torch.Tensor] = None):
+        x = self.project_in(x)
+        x = ops.DwConvGateFn.apply(x, self.dwconv.weight)   # dwconv + chunk + gelu(x1)*x2 fused
+        return self.project_out(x, residual)
+
+
+##########################################################################
+## Multi-DConv Head Transposed Self-Attention (reference net/model.py:105-138)
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads, bias):
+        super().__init__()
+        if dim % num_heads:
+            raise ValueError("dim must be divisible by num_heads")
+        self.num_heads = num_heads
+        self.temperature = nn.Parameter(torch.ones(num_heads, 1, 1))
+        self.qkv = Conv1x1(dim, dim * 3, bias=bias)
+        self.qkv_dwconv = DepthwiseConv3x3(dim * 3, bias=bias)
+        self.project_out = Conv1x1(dim, dim, bias=bias)
+
+    def forward(self, x, residual: Optional[torch.Tensor] = None):
+        qkv = self.qkv_dwconv(self.qkv(x))
+        out = ops.MdtaCoreFn.apply(qkv, self.temperature, self.num_heads)
+        return self.project_out(out, residual)
+
+
+##########################################################################
+## Resizing modules (reference net/model.py:160-178)
+class Downsample(nn.Module):
+    def __init__(self, n_feat):
+        super().__init__()
+        self.body = nn.Sequential(Conv3x3(n_feat, n_feat // 2), PixelUnshuffle2())
+
+    def forward(self, x):
+        return self.body(x)
+
+
+class Upsample(nn.Module):
+    def __init__(self, n_feat):
+        super().__init__()
+        self.body = nn.Sequential(Conv3x3(n_feat, n_feat * 2), PixelShuffle2())
+
+    def forward(self, x):
+        return self.body(x)
+
+
+##########################################################################
+## Transformer Block (reference net/model.py:183-196)
+class TransformerBlock(nn.Module):
+    def __init__(self, dim, num_heads, ffn_expansion_factor, bias, LayerNorm_type):
+        super().__init__()
+        self.norm1 = LayerNorm(dim, LayerNorm_type)
+        self.attn = Attention(dim, num_heads, bias)
+        self.norm2 = LayerNorm(dim, LayerNorm_type)
+        self.ffn = FeedForward(dim, ffn_expansion_factor, bias)
+
+    def forward(self, x):
+        x = self.attn(self.norm1(x), residual=x)   # residual add fused into project_out's epilogue
+        x = self.ffn(self.norm2(x), residual=x)
+        return x
+
+
+##########################################################################
+## Overlapped image patch embedding with 3x3 Conv (reference net/model.py:202-211)
+class OverlapPatchEmbed(nn.Module):
+    def __init__(self, in_c=3, embed_dim=48, bias=False):
+        super().__init__()
+        self.proj = Conv3x3(in_c, embed_dim, bias=bias)
+
+    def forward(self, x):
+        return self.proj(x)
+
+
+class _LinearParams(nn.Module):
+    """nn.Linear parameter holder (weight [out,in], bias [out]) with nn.Linear's default init."""
+
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1 / math.sqrt(in_features)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+##########################################################################
+## Prompt Gen Module (reference net/model.py:218-235)
+class PromptGenBlock(nn.Module):
+    def __init__(self, prompt_dim=128, prompt_len=5, prompt_size=96, lin_dim=192):
+        super().__init__()
+        self.prompt_param = nn.Parameter(torch.rand(1, prompt_len, prompt_dim, prompt_size, prompt_size))
+        self.linear_layer = _LinearParams(lin_dim, prompt_len)
+        self.conv3x3 = Conv3x3(prompt_dim, prompt_dim)
+
+    def forward(self, x):
+        _check_channels(x, self.linear_layer.in_features, "PromptGenBlock")
+        prompt = ops.PromptGenFn.apply(x, self.prompt_param, self.linear_layer.weight, self.linear_layer.bias)
+        return self.conv3x3(prompt)
+
+
+def _cat(a, b):
+    return ops.CatChannelsFn.apply(a, b)
+
+
+##########################################################################
+## PromptIR (reference net/model.py:244-380)
+class PromptIR(nn.Module):
+    def __init__(self,
+                 inp_channels=3,
+                 out_channels=3,
+                 dim=48,
+                 num_blocks=[4, 6, 6, 8],
+                 num_refinement_blocks=4,
+                 heads=[1, 2, 4, 8],
+                 ffn_expansion_factor=2.66,
+                 bias=False,
+                 LayerNorm_type='WithBias',
+                 decoder=False,
+                 ):
+        super().__init__()
+
+        def stage(width, n_heads, count):
+            return nn.Sequential(*[TransformerBlock(dim=width, num_heads=n_heads,
+                                                    ffn_expansion_factor=ffn_expansion_factor, bias=bias,
+                                                    LayerNorm_type=LayerNorm_type) for _ in range(count)])
+
+        self.patch_embed = OverlapPatchEmbed(inp_channels, dim)
+        self.decoder = decoder
+        if self.decoder:
+            self.prompt1 = PromptGenBlock(prompt_dim=64, prompt_len=5, prompt_size=64, lin_dim=96)
+            self.prompt2 = PromptGenBlock(prompt_dim=128, prompt_len=5, prompt_size=32, lin_dim=192)
+            self.prompt3 = PromptGenBlock(prompt_dim=320, prompt_len=5, prompt_size=16, lin_dim=384)
+
+        # present in the reference's state_dict but never used by its forward (net/model.py:271-273,277,282,287)
+        self.chnl_reduce1 = Conv1x1(64, 64, bias=bias)
+        self.chnl_reduce2 = Conv1x1(128, 128, bias=bias)
+        self.chnl_reduce3 = Conv1x1(320, 256, bias=bias)
+        self.reduce_noise_channel_1 = Conv1x1(dim + 64, dim, bias=bias)
+        self.encoder_level1 = stage(dim, heads[0], num_blocks[0])
+        self.down1_2 = Downsample(dim)
+        self.reduce_noise_channel_2 = Conv1x1(int(dim * 2 ** 1) + 128, int(dim * 2 ** 1), bias=bias)
+        self.encoder_level2 = stage(int(dim * 2 ** 1), heads[1], num_blocks[1])
+        self.down2_3 = Downsample(int(dim * 2 ** 1))
+        self.reduce_noise_channel_3 = Conv1x1(int(dim * 2 ** 2) + 256, int(dim * 2 ** 2), bias=bias)
+        self.encoder_level3 = stage(int(dim * 2 ** 2), heads[2], num_blocks[2])
+        self.down3_4 = Downsample(int(dim * 2 ** 2))
+        self.latent = stage(int(dim * 2 ** 3), heads[3], num_blocks[3])
+
+        self.up4_3 = Upsample(int(dim * 2 ** 2))
+        self.reduce_chan_level3 = Conv1x1(int(dim * 2 ** 1) + 192, int(dim * 2 ** 2), bias=bias)
+        self.noise_level3 = TransformerBlock(dim=int(dim * 2 ** 2) + 512, num_heads=heads[2],
+                                             ffn_expansion_factor=ffn_expansion_factor, bias=bias,
+                                             LayerNorm_type=LayerNorm_type)
+        self.reduce_noise_level3 = Conv1x1(int(dim * 2 ** 2) + 512, int(dim * 2 ** 2), bias=bias)
+        self.decoder_level3 = stage(int(dim * 2 ** 2), heads[2], num_blocks[2])
+
+        self.up3_2 = Upsample(int(dim * 2 ** 2))
+        self.reduce_chan_level2 = Conv1x1(int(dim * 2 ** 2), int(dim * 2 ** 1), bias=bias)
+        self.noise_level2 = TransformerBlock(dim=int(dim * 2 ** 1) + 224, num_heads=heads[2],
+                                             ffn_expansion_factor=ffn_expansion_factor, bias=bias,
+                                             LayerNorm_type=LayerNorm_type)
+        self.reduce_noise_level2 = Conv1x1(int(dim * 2 ** 1) + 224, int(dim * 2 ** 2), bias=bias)
+        self.decoder_level2 = stage(int(dim * 2 ** 1), heads[1], num_blocks[1])
+
+        self.up2_1 = Upsample(int(dim * 2 ** 1))
+        self.noise_level1 = TransformerBlock(dim=int(dim * 2 ** 1) + 64, num_heads=heads[2],
+                                             ffn_expansion_factor=ffn_expansion_factor, bias=bias,
+                                             LayerNorm_type=LayerNorm_type)
+        self.reduce_noise_level1 = Conv1x1(int(dim * 2 ** 1) + 64, int(dim * 2 ** 1), bias=bias)
+        self.decoder_level1 = stage(int(dim * 2 ** 1), heads[0], num_blocks[0])
+        self.refinement = stage(int(dim * 2 ** 1), heads[0], num_refinement_blocks)
+        self.output = Conv3x3(int(dim * 2 ** 1), out_channels, bias=bias)
+
+    def forward(self, inp_img, noise_emb=None):
+        if inp_img.dim() != 4:
+            raise RuntimeError(f"PromptIR expects a [B, C, H, W] tensor, got {list(inp_img.shape)}")
+        if inp_img.shape[2] % 8 or inp_img.shape[3] % 8:
+            raise RuntimeError("pixel_unshuffle expects height and width to be divisible by 2 at every level: "
+                               f"H, W must be multiples of 8, got {list(inp_img.shape[2:])}")
+        ops._require_gpu(inp_img)
+
+        inp_enc_level1 = self.patch_embed(inp_img)
+        out_enc_level1 = self.encoder_level1(inp_enc_level1)
+        out_enc_level2 = self.encoder_level2(self.down1_2(out_enc_level1))
+        out_enc_level3 = self.encoder_level3(self.down2_3(out_enc_level2))
+        latent = self.latent(self.down3_4(out_enc_level3))
+        if self.decoder:
+            latent = _cat(latent, self.prompt3(latent))
+            latent = self.reduce_noise_level3(self.noise_level3(latent))
+
+        inp_dec_level3 = _cat(self.up4_3(latent), out_enc_level3)
+        out_dec_level3 = self.decoder_level3(self.reduce_chan_level3(inp_dec_level3))
+        if self.decoder:
+            out_dec_level3 = _cat(out_dec_level3, self.prompt2(out_dec_level3))
+            out_dec_level3 = self.reduce_noise_level2(self.noise_level2(out_dec_level3))
+
+        inp_dec_level2 = _cat(self.up3_2(out_dec_level3), out_enc_level2)
+        out_dec_level2 = self.decoder_level2(self.reduce_chan_level2(inp_dec_level2))
+        if self.decoder:
+            out_dec_level2 = _cat(out_dec_level2, self.prompt1(out_dec_level2))
+            out_dec_level2 = self.reduce_noise_level1(self.noise_level1(out_dec_level2))
+
+        inp_dec_level1 = _cat(self.up2_1(out_dec_level2), out_enc_level1)
+        out_dec_level1 = self.refinement(self.decoder_level1(inp_dec_level1))
+        return self.output(out_dec_level1, residual=inp_img)   # `+ inp_img` fused into the conv epilogue

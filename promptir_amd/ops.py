@@ -1,0 +1,567 @@
+"""Operator layer: torch tensors in, HIP kernels (C ABI, promptir_amd/_lib.py) underneath.
+
+PyTorch supplies device memory, the current HIP stream and autograd bookkeeping only;
+every FLOP of the PromptIR path runs in libpromptir_hip.so.  Tensors must live on a
+ROCm device — there is no CPU or eager fallback (see `_require_gpu`).
+
+Layout contract for activations: fp32 NCHW with stride(3)==1, stride(2)==W,
+stride(1)==H*W; the batch stride is free, so channel slices of a larger buffer
+(q/k/v inside qkv, halves of a concat) are passed without copies.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+
+# ----------------------------------------------------------------------------- plumbing
+def _require_gpu(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "promptir_amd: the HIP path needs tensors on a ROCm device (got %s); there is no CPU "
+                "fallback — use oracle/ for CPU reference results" % t.device)
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"promptir_amd: fp32 only (the reference uses no AMP), got {t.dtype}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _planes(t: torch.Tensor) -> torch.Tensor:
+    """Return `t` if it satisfies the plane layout (free batch stride), else a contiguous copy."""
+    if t.dim() != 4:
+        raise RuntimeError(f"expected a 4-d NCHW tensor, got shape {tuple(t.shape)}")
+    b, c, h, w = t.shape
+    st = t.stride()
+    ok = (w == 1 or st[3] == 1) and (h == 1 or st[2] == w) and (c == 1 or st[1] == h * w)
+    if ok and (b == 1 or st[0] >= c * h * w):
+        return t
+    return t.contiguous()
+
+
+def _bs(t: torch.Tensor) -> int:
+    return t.stride(0) if t.shape[0] > 1 else t.shape[1] * t.shape[2] * t.shape[3]
+
+
+_WS = {}
+
+
+def workspace(nfloats: int, device: torch.device, slot: str = "main") -> torch.Tensor:
+    """Grow-only scratch buffer per (device, slot).  All kernels of one op are enqueued on the
+    current stream in order, so one buffer per slot is race-free on a single stream."""
+    key = (device.index, slot, _stream())
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.empty(max(int(nfloats), 1 << 16), dtype=torch.float32, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# ----------------------------------------------------------------------------- raw kernels (no autograd)
+def gemm_nn(A: torch.Tensor, a_batch: Tuple[int, int], a_sm: int, a_sk: int,
+            X: torch.Tensor, x_off: int, x_batch: Tuple[int, int], ldx: int,
+            Y: torch.Tensor, y_off: int, y_batch: Tuple[int, int], ldy: int,
+            M: int, K: int, N: int, O1: int, O2: int,
+            R: Optional[torch.Tensor] = None, r_off: int = 0, r_batch: Tuple[int, int] = (0, 0), ldr: int = 0,
+            rowscale: Optional[torch.Tensor] = None, rs_batch: Tuple[int, int] = (0, 0)) -> None:
+    g = _lib.GemmNN()
+    g.A, g.a_s1, g.a_s2, g.a_sm, g.a_sk = A.data_ptr(), a_batch[0], a_batch[1], a_sm, a_sk
+    g.X, g.x_s1, g.x_s2, g.ldx = X.data_ptr() + 4 * x_off, x_batch[0], x_batch[1], ldx
+    g.Y, g.y_s1, g.y_s2, g.ldy = Y.data_ptr() + 4 * y_off, y_batch[0], y_batch[1], ldy
+    if R is not None:
+        g.R, g.r_s1, g.r_s2, g.ldr = R.data_ptr() + 4 * r_off, r_batch[0], r_batch[1], ldr
+    if rowscale is not None:
+        g.rowscale, g.rs_s1, g.rs_s2 = rowscale.data_ptr(), rs_batch[0], rs_batch[1]
+    g.M, g.K, g.N, g.O1, g.O2 = M, K, N, O1, O2
+    check(lib.pir_gemm_nn(C.byref(g), _stream()), "pir_gemm_nn")
+
+
+def gemm_nt(X: torch.Tensor, x_off: int, x_str: Tuple[int, int, int], ldx: int,
+            Y: torch.Tensor, y_off: int, y_str: Tuple[int, int, int], ldy: int,
+            G: torch.Tensor, g_off: int, g_str: Tuple[int, int, int],
+            M1: int, M2: int, N: int, O1: int, O2: int, BR: int,
+            shift: Optional[Tuple[int, int, int, int]] = None, alpha: float = 1.0, accumulate: bool = False) -> None:
+    nws = lib.pir_gemm_nt_ws_floats(M1, M2, N, O1 * O2, BR)
+    ws = workspace(nws, X.device)
+    g = _lib.GemmNT()
+    g.X, g.x_s1, g.x_s2, g.x_sr, g.ldx = X.data_ptr() + 4 * x_off, x_str[0], x_str[1], x_str[2], ldx
+    g.Y, g.y_s1, g.y_s2, g.y_sr, g.ldy = Y.data_ptr() + 4 * y_off, y_str[0], y_str[1], y_str[2], ldy
+    g.G, g.g_so, g.g_si, g.g_sj = G.data_ptr() + 4 * g_off, g_str[0], g_str[1], g_str[2]
+    g.M1, g.M2, g.N, g.O1, g.O2, g.BR = M1, M2, N, O1, O2, BR
+    if shift is not None:
+        g.shift_dh, g.shift_dw, g.H, g.W = shift
+    g.ws, g.ws_floats = ws.data_ptr(), ws.numel()
+    g.alpha, g.accumulate = alpha, int(accumulate)
+    check(lib.pir_gemm_nt(C.byref(g), _stream()), "pir_gemm_nt")
+
+
+def conv1x1_forward(x: torch.Tensor, w: torch.Tensor, residual: Optional[torch.Tensor] = None,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y[b] = W x[b] (+ residual[b]);  w is [Cout, Cin] or [Cout, Cin, 1, 1]."""
+    x = _planes(x)
+    b, cin, h, wd = x.shape
+    cout = w.shape[0]
+    hw = h * wd
+    if out is None:
+        out = torch.empty((b, cout, h, wd), dtype=torch.float32, device=x.device)
+    if residual is not None:
+        residual = _planes(residual)
+    gemm_nn(w, (0, 0), cin, 1, x, 0, (_bs(x), 0), hw, out, 0, (_bs(out), 0), hw, cout, cin, hw, b, 1,
+            R=residual, r_batch=(_bs(residual), 0) if residual is not None else (0, 0), ldr=hw)
+    return out
+
+
+def conv1x1_dgrad(dy: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx[b] = W^T dy[b]."""
+    dy = _planes(dy)
+    b, cout, h, wd = dy.shape
+    cin = w.shape[1]
+    hw = h * wd
+    if out is None:
+        out = torch.empty((b, cin, h, wd), dtype=torch.float32, device=dy.device)
+    gemm_nn(w, (0, 0), 1, cin, dy, 0, (_bs(dy), 0), hw, out, 0, (_bs(out), 0), hw, cin, cout, hw, b, 1)
+    return out
+
+
+def conv1x1_wgrad(dy: torch.Tensor, x: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+    """dW = sum_b dy[b] x[b]^T, shaped like the weight."""
+    dy, x = _planes(dy), _planes(x)
+    b, cout, h, wd = dy.shape
+    cin = x.shape[1]
+    hw = h * wd
+    dw = torch.empty_like(like, memory_format=torch.contiguous_format)
+    gemm_nt(dy, 0, (0, 0, _bs(dy)), hw, x, 0, (0, 0, _bs(x)), hw, dw, 0, (0, cin, 1), cout, cin, hw, 1, 1, b)
+    return dw
+
+
+def conv3x3_forward(x: torch.Tensor, w: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    x = _planes(x)
+    b, cin, h, wd = x.shape
+    cout = w.shape[0]
+    out = torch.empty((b, cout, h, wd), dtype=torch.float32, device=x.device)
+    if residual is not None:
+        residual = _planes(residual)
+    check(lib.pir_conv3x3(w.data_ptr(), 1, cin * 9, 9, 0, x.data_ptr(), _bs(x), out.data_ptr(), _bs(out),
+                          _p(residual), _bs(residual) if residual is not None else 0,
+                          b, cout, cin, h, wd, _stream()), "pir_conv3x3")
+    return out
+
+
+def conv3x3_dgrad(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    dy = _planes(dy)
+    b, cout, h, wd = dy.shape
+    cin = w.shape[1]
+    out = torch.empty((b, cin, h, wd), dtype=torch.float32, device=dy.device)
+    # A(tap, m=cin, k=cout) = w[k][m][8-tap]
+    check(lib.pir_conv3x3(w.data_ptr(), 1, 9, cin * 9, 1, dy.data_ptr(), _bs(dy), out.data_ptr(), _bs(out),
+                          None, 0, b, cin, cout, h, wd, _stream()), "pir_conv3x3(dgrad)")
+    return out
+
+
+def conv3x3_wgrad(dy: torch.Tensor, x: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+    dy, x = _planes(dy), _planes(x)
+    b, cout, h, wd = dy.shape
+    cin = x.shape[1]
+    hw = h * wd
+    dw = torch.empty_like(like, memory_format=torch.contiguous_format)
+    for tap in range(9):
+        gemm_nt(dy, 0, (0, 0, _bs(dy)), hw, x, 0, (0, 0, _bs(x)), hw, dw, tap, (0, cin * 9, 9),
+                cout, cin, hw, 1, 1, b, shift=(tap // 3 - 1, tap % 3 - 1, h, wd))
+    return dw
+
+
+def layernorm_forward(x, weight, bias):
+    x = _planes(x)
+    b, c, h, w = x.shape
+    y = torch.empty((b, c, h, w), dtype=torch.float32, device=x.device)
+    mean = torch.empty((b, h * w), dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    check(lib.pir_layernorm_fwd(x.data_ptr(), _bs(x), weight.data_ptr(), _p(bias), y.data_ptr(), _bs(y),
+                                mean.data_ptr(), rstd.data_ptr(), b, c, h * w, _stream()), "pir_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_backward(dy, x, weight, with_bias, mean, rstd):
+    dy, x = _planes(dy), _planes(x)
+    b, c, h, w = x.shape
+    dx = torch.empty((b, c, h, w), dtype=torch.float32, device=x.device)
+    dweight = torch.empty_like(weight)
+    dbias = torch.empty_like(weight) if with_bias else None
+    nws = lib.pir_layernorm_bwd_ws_floats(b, c, h * w)
+    ws = workspace(nws, x.device)
+    check(lib.pir_layernorm_bwd(dy.data_ptr(), _bs(dy), x.data_ptr(), _bs(x), weight.data_ptr(), int(with_bias),
+                                mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _bs(dx), dweight.data_ptr(),
+                                _p(dbias), ws.data_ptr(), ws.numel(), b, c, h * w, _stream()), "pir_layernorm_bwd")
+    return dx, dweight, dbias
+
+
+def dwconv_forward(x, w, flip=False, out=None):
+    x = _planes(x)
+    b, c, h, wd = x.shape
+    if out is None:
+        out = torch.empty((b, c, h, wd), dtype=torch.float32, device=x.device)
+    check(lib.pir_dwconv3x3(x.data_ptr(), _bs(x), w.data_ptr(), int(flip), out.data_ptr(), _bs(out),
+                            b, c, h, wd, _stream()), "pir_dwconv3x3")
+    return out
+
+
+def dwconv_wgrad(dy, x, like):
+    dy, x = _planes(dy), _planes(x)
+    b, c, h, wd = x.shape
+    dw = torch.empty_like(like, memory_format=torch.contiguous_format)
+    nws = lib.pir_dwconv3x3_wgrad_ws_floats(b, c, h, wd)
+    ws = workspace(nws, x.device)
+    check(lib.pir_dwconv3x3_wgrad(dy.data_ptr(), _bs(dy), x.data_ptr(), _bs(x), dw.data_ptr(), ws.data_ptr(),
+                                  ws.numel(), b, c, h, wd, _stream()), "pir_dwconv3x3_wgrad")
+    return dw
+
+
+def dwconv_gate_forward(x, w):
+    x = _planes(x)
+    b, c2, h, wd = x.shape
+    hid = c2 // 2
+    g = torch.empty((b, hid, h, wd), dtype=torch.float32, device=x.device)
+    check(lib.pir_dwconv3x3_gate(x.data_ptr(), _bs(x), w.data_ptr(), g.data_ptr(), _bs(g), b, hid, h, wd, _stream()),
+          "pir_dwconv3x3_gate")
+    return g
+
+
+def dwconv_gate_backward(x, w, dg):
+    x, dg = _planes(x), _planes(dg)
+    b, c2, h, wd = x.shape
+    hid = c2 // 2
+    dt = torch.empty((b, c2, h, wd), dtype=torch.float32, device=x.device)
+    check(lib.pir_dwconv3x3_gate_bwd(x.data_ptr(), _bs(x), w.data_ptr(), dg.data_ptr(), _bs(dg), dt.data_ptr(),
+                                     _bs(dt), b, hid, h, wd, _stream()), "pir_dwconv3x3_gate_bwd")
+    return dt
+
+
+def reduce_partials(parts, stride, count_parts, out, count, alpha=1.0, accumulate=False):
+    check(lib.pir_reduce_partials(parts.data_ptr(), stride, count_parts, alpha, int(accumulate), out.data_ptr(), count,
+                                  _stream()), "pir_reduce_partials")
+
+
+def copy_planes(src, dst, accumulate=False):
+    """dst[b, :C] (a channel slice of a larger buffer is fine) = src[b, :C]."""
+    src, = (_planes(src),)
+    b, c, h, w = src.shape
+    assert dst.shape == src.shape
+    check(lib.pir_copy_planes(src.data_ptr(), _bs(src), dst.data_ptr(), _bs(dst), int(accumulate), b, c * h * w,
+                              _stream()), "pir_copy_planes")
+
+
+def mdta_core_forward(qkv: torch.Tensor, temperature: torch.Tensor, heads: int):
+    """From qkv = dw3x3(1x1(x)) to out = softmax(norm(q) norm(k)^T * t) v (net/model.py:121-135)."""
+    qkv = _planes(qkv)
+    b, c3, h, w = qkv.shape
+    c_all = c3 // 3
+    c = c_all // heads
+    hw = h * w
+    dev = qkv.device
+    bs = _bs(qkv)
+    sumsq = torch.empty((b, 2 * c_all), dtype=torch.float32, device=dev)
+    check(lib.pir_row_sumsq(qkv.data_ptr(), bs, sumsq.data_ptr(), b, 2 * c_all, hw, _stream()), "pir_row_sumsq")
+    gram = torch.empty((b, heads, c, c), dtype=torch.float32, device=dev)
+    gemm_nt(qkv, 0, (bs, c * hw, 0), hw, qkv, c_all * hw, (bs, c * hw, 0), hw, gram, 0, (c * c, c, 1),
+            c, c, hw, b, heads, 1)
+    attn = torch.empty_like(gram)
+    check(lib.pir_mdta_softmax_fwd(gram.data_ptr(), sumsq.data_ptr(), temperature.data_ptr(), attn.data_ptr(),
+                                   b, heads, c, _stream()), "pir_mdta_softmax_fwd")
+    out = torch.empty((b, c_all, h, w), dtype=torch.float32, device=dev)
+    gemm_nn(attn, (heads * c * c, c * c), c, 1, qkv, 2 * c_all * hw, (bs, c * hw), hw,
+            out, 0, (c_all * hw, c * hw), hw, c, c, hw, b, heads)
+    return out, attn, gram, sumsq
+
+
+def mdta_core_backward(dout, qkv, temperature, heads, attn, gram, sumsq):
+    dout, qkv = _planes(dout), _planes(qkv)
+    b, c3, h, w = qkv.shape
+    c_all = c3 // 3
+    c = c_all // heads
+    hw = h * w
+    dev = qkv.device
+    bs, dbs = _bs(qkv), _bs(dout)
+    dqkv = torch.empty((b, c3, h, w), dtype=torch.float32, device=dev)
+    qbs = c3 * hw
+    # dA = dout v^T
+    dattn = torch.empty_like(attn)
+    gemm_nt(dout, 0, (dbs, c * hw, 0), hw, qkv, 2 * c_all * hw, (bs, c * hw, 0), hw, dattn, 0, (c * c, c, 1),
+            c, c, hw, b, heads, 1)
+    # dv = A^T dout :  A'(m=j, k=i) = attn[i*c + j]
+    gemm_nn(attn, (heads * c * c, c * c), 1, c, dout, 0, (dbs, c * hw), hw,
+            dqkv, 2 * c_all * hw, (qbs, c * hw), hw, c, c, hw, b, heads)
+    dgram = torch.empty_like(attn)
+    alpha_q = torch.empty((b, c_all), dtype=torch.float32, device=dev)
+    alpha_k = torch.empty_like(alpha_q)
+    dtemp_part = torch.empty((b, heads), dtype=torch.float32, device=dev)
+    check(lib.pir_mdta_softmax_bwd(dattn.data_ptr(), attn.data_ptr(), gram.data_ptr(), sumsq.data_ptr(),
+                                   temperature.data_ptr(), dgram.data_ptr(), alpha_q.data_ptr(), alpha_k.data_ptr(),
+                                   dtemp_part.data_ptr(), b, heads, c, _stream()), "pir_mdta_softmax_bwd")
+    # dq = dG k + alpha_q * q
+    gemm_nn(dgram, (heads * c * c, c * c), c, 1, qkv, c_all * hw, (bs, c * hw), hw,
+            dqkv, 0, (qbs, c * hw), hw, c, c, hw, b, heads,
+            R=qkv, r_off=0, r_batch=(bs, c * hw), ldr=hw, rowscale=alpha_q, rs_batch=(c_all, c))
+    # dk = dG^T q + alpha_k * k
+    gemm_nn(dgram, (heads * c * c, c * c), 1, c, qkv, 0, (bs, c * hw), hw,
+            dqkv, c_all * hw, (qbs, c * hw), hw, c, c, hw, b, heads,
+            R=qkv, r_off=c_all * hw, r_batch=(bs, c * hw), ldr=hw, rowscale=alpha_k, rs_batch=(c_all, c))
+    dtemp = torch.empty_like(temperature)
+    reduce_partials(dtemp_part, heads, b, dtemp, heads)
+    return dqkv, dtemp
+
+
+def pixel_unshuffle(x):
+    x = _planes(x)
+    b, c, h2, w2 = x.shape
+    h, w = h2 // 2, w2 // 2
+    if h2 % 2 or w2 % 2:
+        raise RuntimeError("pixel_unshuffle expects height and width to be divisible by 2")
+    y = torch.empty((b, c * 4, h, w), dtype=torch.float32, device=x.device)
+    check(lib.pir_pixel_unshuffle2(x.data_ptr(), _bs(x), y.data_ptr(), _bs(y), b, c, h, w, _stream()),
+          "pir_pixel_unshuffle2")
+    return y
+
+
+def pixel_shuffle(x):
+    x = _planes(x)
+    b, c4, h, w = x.shape
+    c = c4 // 4
+    y = torch.empty((b, c, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    check(lib.pir_pixel_shuffle2(x.data_ptr(), _bs(x), y.data_ptr(), _bs(y), b, c, h, w, _stream()),
+          "pir_pixel_shuffle2")
+    return y
+
+
+# ----------------------------------------------------------------------------- autograd Functions
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _require_gpu(x, weight, bias)
+        y, mean, rstd = layernorm_forward(x, weight, bias)
+        ctx.with_bias = bias is not None
+        ctx.save_for_backward(x, weight, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, mean, rstd = ctx.saved_tensors
+        dx, dw, db = layernorm_backward(dy, x, weight, ctx.with_bias, mean, rstd)
+        return dx, dw, db
+
+
+class Conv1x1Fn(torch.autograd.Function):
+    """y = W x (+ residual).  W: [Cout, Cin, 1, 1]."""
+
+    @staticmethod
+    def forward(ctx, x, w, residual):
+        _require_gpu(x, w, residual)
+        ctx.save_for_backward(x, w)
+        ctx.has_res = residual is not None
+        return conv1x1_forward(x, w, residual)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = conv1x1_dgrad(dy, w) if ctx.needs_input_grad[0] else None
+        dw = conv1x1_wgrad(dy, x, w) if ctx.needs_input_grad[1] else None
+        return dx, dw, (dy if ctx.has_res and ctx.needs_input_grad[2] else None)
+
+
+class Conv3x3Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, residual):
+        _require_gpu(x, w, residual)
+        ctx.save_for_backward(x, w)
+        ctx.has_res = residual is not None
+        return conv3x3_forward(x, w, residual)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = conv3x3_dgrad(dy, w) if ctx.needs_input_grad[0] else None
+        dw = conv3x3_wgrad(dy, x, w) if ctx.needs_input_grad[1] else None
+        return dx, dw, (dy if ctx.has_res and ctx.needs_input_grad[2] else None)
+
+
+class DwConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        _require_gpu(x, w)
+        ctx.save_for_backward(x, w)
+        return dwconv_forward(x, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = dwconv_forward(dy, w, flip=True) if ctx.needs_input_grad[0] else None
+        dw = dwconv_wgrad(dy, x, w) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+class DwConvGateFn(torch.autograd.Function):
+    """g = gelu(dw(x)[:hid]) * dw(x)[hid:]; the pre-gate tensor is recomputed in backward."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        _require_gpu(x, w)
+        ctx.save_for_backward(x, w)
+        return dwconv_gate_forward(x, w)
+
+    @staticmethod
+    def backward(ctx, dg):
+        x, w = ctx.saved_tensors
+        dt = dwconv_gate_backward(x, w, dg)
+        dx = dwconv_forward(dt, w, flip=True) if ctx.needs_input_grad[0] else None
+        dw = dwconv_wgrad(dt, x, w) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+class MdtaCoreFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, temperature, heads):
+        _require_gpu(qkv, temperature)
+        out, attn, gram, sumsq = mdta_core_forward(qkv, temperature, heads)
+        ctx.heads = heads
+        ctx.save_for_backward(qkv, temperature, attn, gram, sumsq)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, temperature, attn, gram, sumsq = ctx.saved_tensors
+        dqkv, dtemp = mdta_core_backward(dout, qkv, temperature, ctx.heads, attn, gram, sumsq)
+        return dqkv, dtemp, None
+
+
+class PixelUnshuffleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        return pixel_unshuffle(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return pixel_shuffle(dy)
+
+
+class PixelShuffleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        return pixel_shuffle(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return pixel_unshuffle(dy)
+
+
+class CatChannelsFn(torch.autograd.Function):
+    """torch.cat([a, b], 1) (net/model.py:341,347,353,359,365,370) as two plane copies."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _require_gpu(a, b)
+        ctx.ca = a.shape[1]
+        out = torch.empty((a.shape[0], a.shape[1] + b.shape[1], a.shape[2], a.shape[3]), dtype=torch.float32,
+                          device=a.device)
+        copy_planes(a, out[:, :ctx.ca])
+        copy_planes(b, out[:, ctx.ca:])
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy[:, :ctx.ca], dy[:, ctx.ca:]
+
+
+class PromptGenFn(torch.autograd.Function):
+    """x -> bilinear(sum_l softmax(Linear(mean(x)))_l * P_l) (net/model.py:226-232); the 3x3 conv follows."""
+
+    @staticmethod
+    def forward(ctx, x, prompt_param, lin_w, lin_b):
+        _require_gpu(x, prompt_param, lin_w, lin_b)
+        x = _planes(x)
+        b, c, h, w = x.shape
+        _, L, D, S, _ = prompt_param.shape
+        dev = x.device
+        emb = torch.empty((b, c), dtype=torch.float32, device=dev)
+        check(lib.pir_spatial_mean(x.data_ptr(), _bs(x), emb.data_ptr(), b, c, h * w, _stream()), "pir_spatial_mean")
+        mix = torch.empty((b, L), dtype=torch.float32, device=dev)
+        check(lib.pir_prompt_mix_fwd(emb.data_ptr(), lin_w.data_ptr(), lin_b.data_ptr(), mix.data_ptr(), b, c, L,
+                                     _stream()), "pir_prompt_mix_fwd")
+        out = torch.empty((b, D, h, w), dtype=torch.float32, device=dev)
+        check(lib.pir_prompt_resize_fwd(mix.data_ptr(), prompt_param.data_ptr(), out.data_ptr(), _bs(out),
+                                        b, L, D, S, h, w, _stream()), "pir_prompt_resize_fwd")
+        ctx.save_for_backward(emb, mix, prompt_param, lin_w)
+        ctx.x_shape = (b, c, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        emb, mix, prompt_param, lin_w = ctx.saved_tensors
+        dout = _planes(dout)
+        b, c, h, w = ctx.x_shape
+        _, L, D, S, _ = prompt_param.shape
+        dev = dout.device
+        dP = torch.empty_like(prompt_param)
+        dmix = torch.empty_like(mix)
+        nws = lib.pir_prompt_resize_bwd_ws_floats(b, L, D, S, h, w)
+        ws = workspace(nws, dev)
+        check(lib.pir_prompt_resize_bwd(dout.data_ptr(), _bs(dout), mix.data_ptr(), prompt_param.data_ptr(),
+                                        dP.data_ptr(), dmix.data_ptr(), ws.data_ptr(), ws.numel(),
+                                        b, L, D, S, h, w, _stream()), "pir_prompt_resize_bwd")
+        dWl = torch.empty_like(lin_w)
+        dbl = torch.empty((L,), dtype=torch.float32, device=dev)
+        dx = torch.empty((b, c, h, w), dtype=torch.float32, device=dev)
+        check(lib.pir_prompt_mix_bwd(dmix.data_ptr(), mix.data_ptr(), emb.data_ptr(), lin_w.data_ptr(),
+                                     dWl.data_ptr(), dbl.data_ptr(), dx.data_ptr(), _bs(dx), 0, b, c, L, h * w,
+                                     _stream()), "pir_prompt_mix_bwd")
+        return dx, dP, dWl, dbl
+
+
+class L1LossFn(torch.autograd.Function):
+    """nn.L1Loss() (train.py:32,43); the gradient is produced in the same pass as the loss."""
+
+    @staticmethod
+    def forward(ctx, restored, clean):
+        _require_gpu(restored, clean)
+        restored, clean = restored.contiguous(), clean.contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=restored.device)
+        ws = workspace(1024, restored.device, slot="loss")
+        check(lib.pir_l1_loss(restored.data_ptr(), clean.data_ptr(), loss.data_ptr(), None, 1.0,
+                              ws.data_ptr(), restored.numel(), _stream()), "pir_l1_loss")
+        ctx.save_for_backward(restored, clean)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        restored, clean = ctx.saved_tensors
+        grad = torch.empty_like(restored)
+        dloss = dloss.contiguous()
+        check(lib.pir_l1_loss_grad(restored.data_ptr(), clean.data_ptr(), dloss.data_ptr(), grad.data_ptr(),
+                                   restored.numel(), _stream()), "pir_l1_loss_grad")
+        return grad, None
+
+
+def l1_loss(restored: torch.Tensor, clean: torch.Tensor) -> torch.Tensor:
+    return L1LossFn.apply(restored, clean)
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, step, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+               grad_scale=1.0):
+    """torch.optim.AdamW defaults as used at train.py:53, applied to flat fp32 buffers in place."""
+    _require_gpu(param, grad, exp_avg, exp_avg_sq)
+    check(lib.pir_adamw_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                             param.numel(), lr, betas[0], betas[1], eps, weight_decay, step, grad_scale, _stream()),
+          "pir_adamw_step")

@@ -1,0 +1,180 @@
+"""Kernel-level parity through the C ABI on ragged / edge shapes the model fixtures do not reach.
+
+Reference = plain PyTorch fp32 CPU ops of the same arithmetic (these are floating-point kernels).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from promptir_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rnd(name, *shape, seed=0):
+    return torch.from_numpy((W.uniform01(name, int(np.prod(shape)), seed).reshape(shape) * 2 - 1).astype(np.float32))
+
+
+def close(a, b, rtol=2e-5):
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a.cpu() - b).abs().max())
+    assert err <= rtol * scale, (err, scale)
+
+
+@pytest.mark.parametrize("b,cin,cout,h,w", [(2, 48, 144, 16, 16), (1, 127, 48, 9, 11), (3, 5, 3, 8, 24),
+                                            (2, 254, 96, 12, 20), (1, 384, 2042, 4, 4), (2, 33, 70, 1, 7)])
+def test_conv1x1_fwd_bwd(b, cin, cout, h, w):
+    from promptir_amd import ops
+
+    x, wt, r = rnd("x", b, cin, h, w), rnd("w", cout, cin, 1, 1), rnd("r", b, cout, h, w)
+    dy = rnd("dy", b, cout, h, w)
+    y = ops.conv1x1_forward(x.to(DEV), wt.to(DEV), r.to(DEV))
+    close(y, F.conv2d(x, wt) + r)
+    dx = ops.conv1x1_dgrad(dy.to(DEV), wt.to(DEV))
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    F.conv2d(xr, wr).backward(dy)
+    close(dx, xr.grad)
+    dw = ops.conv1x1_wgrad(dy.to(DEV), x.to(DEV), wt.to(DEV))
+    close(dw, wr.grad, rtol=5e-5)
+
+
+def test_conv1x1_channel_slices():
+    """Operands that are channel slices of larger buffers (free batch stride)."""
+    from promptir_amd import ops
+
+    big = rnd("big", 2, 80, 8, 12)
+    wt = rnd("w", 24, 32, 1, 1)
+    out = torch.zeros(2, 64, 8, 12, device=DEV)
+    ops.conv1x1_forward(big.to(DEV)[:, 16:48], wt.to(DEV), out=out[:, 8:32])
+    close(out[:, 8:32], F.conv2d(big[:, 16:48], wt))
+    assert float(out[:, :8].abs().max()) == 0 and float(out[:, 32:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("b,cin,cout,h,w", [(2, 3, 48, 16, 24), (1, 48, 24, 9, 11), (2, 96, 3, 8, 8), (1, 20, 20, 5, 7)])
+def test_conv3x3_fwd_bwd(b, cin, cout, h, w):
+    from promptir_amd import ops
+
+    x, wt, dy = rnd("x", b, cin, h, w), rnd("w", cout, cin, 3, 3), rnd("dy", b, cout, h, w)
+    close(ops.conv3x3_forward(x.to(DEV), wt.to(DEV)), F.conv2d(x, wt, padding=1))
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    F.conv2d(xr, wr, padding=1).backward(dy)
+    close(ops.conv3x3_dgrad(dy.to(DEV), wt.to(DEV)), xr.grad)
+    close(ops.conv3x3_wgrad(dy.to(DEV), x.to(DEV), wt.to(DEV)), wr.grad, rtol=5e-5)
+
+
+@pytest.mark.parametrize("b,c,h,w", [(2, 6, 16, 16), (1, 5, 9, 11), (1, 3, 40, 300), (2, 4, 128, 128), (1, 7, 3, 4),
+                                     (1, 2, 70, 520), (3, 2, 1, 8)])
+def test_dwconv_fwd_bwd(b, c, h, w):
+    from promptir_amd import ops
+
+    x, wt, dy = rnd("x", b, c, h, w), rnd("w", c, 1, 3, 3), rnd("dy", b, c, h, w)
+    close(ops.dwconv_forward(x.to(DEV), wt.to(DEV)), F.conv2d(x, wt, padding=1, groups=c))
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    F.conv2d(xr, wr, padding=1, groups=c).backward(dy)
+    close(ops.dwconv_forward(dy.to(DEV), wt.to(DEV), flip=True), xr.grad)
+    close(ops.dwconv_wgrad(dy.to(DEV), x.to(DEV), wt.to(DEV)), wr.grad, rtol=5e-5)
+
+
+@pytest.mark.parametrize("b,hid,h,w", [(2, 5, 16, 16), (1, 127, 9, 11), (1, 3, 128, 128)])
+def test_dwconv_gate(b, hid, h, w):
+    from promptir_amd import ops
+
+    x, wt, dg = rnd("x", b, 2 * hid, h, w), rnd("w", 2 * hid, 1, 3, 3), rnd("dg", b, hid, h, w)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    t = F.conv2d(xr, wr, padding=1, groups=2 * hid)
+    t.retain_grad()
+    g = F.gelu(t[:, :hid]) * t[:, hid:]
+    g.backward(dg)
+    close(ops.dwconv_gate_forward(x.to(DEV), wt.to(DEV)), g.detach())
+    close(ops.dwconv_gate_backward(x.to(DEV), wt.to(DEV), dg.to(DEV)), t.grad)
+
+
+@pytest.mark.parametrize("b,c,h,w,bias", [(2, 48, 8, 8, True), (1, 704, 4, 6, True), (2, 320, 3, 5, False),
+                                          (1, 96, 16, 16, False), (2, 7, 9, 11, True)])
+def test_layernorm(b, c, h, w, bias):
+    from oracle.promptir_ref import layer_norm
+    from promptir_amd import ops
+
+    x, wt, bs, dy = rnd("x", b, c, h, w) * 3 + 0.5, rnd("w", c) + 1.5, rnd("b", c), rnd("dy", b, c, h, w)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    br = bs.clone().requires_grad_(True) if bias else None
+    y = layer_norm(xr, wr, br)
+    y.backward(dy)
+    yg, mean, rstd = ops.layernorm_forward(x.to(DEV), wt.to(DEV), bs.to(DEV) if bias else None)
+    close(yg, y.detach())
+    dx, dw, db = ops.layernorm_backward(dy.to(DEV), x.to(DEV), wt.to(DEV), bias, mean, rstd)
+    close(dx, xr.grad, rtol=5e-5)
+    close(dw, wr.grad, rtol=5e-5)
+    if bias:
+        close(db, br.grad, rtol=5e-5)
+
+
+@pytest.mark.parametrize("b,c,h,w", [(2, 3, 4, 6), (1, 48, 8, 8)])
+def test_pixel_shuffles(b, c, h, w):
+    from promptir_amd import ops
+
+    hi = rnd("hi", b, c, 2 * h, 2 * w)
+    lo = ops.pixel_unshuffle(hi.to(DEV))
+    assert torch.equal(lo.cpu(), F.pixel_unshuffle(hi, 2))          # pure data movement: bit-exact
+    assert torch.equal(ops.pixel_shuffle(lo).cpu(), hi)               # round trip
+
+
+@pytest.mark.parametrize("heads,c,hw", [(1, 48, 256), (2, 48, 99), (4, 176, 64), (4, 40, 128), (8, 48, 16)])
+def test_mdta_core(heads, c, hw):
+    from promptir_amd import ops
+
+    b, C = 2, heads * c
+    h, w = (hw // 8, 8) if hw % 8 == 0 else (9, 11)
+    qkv, temp, dout = rnd("qkv", b, 3 * C, h, w), rnd("t", heads, 1, 1) * 0.5 + 1.0, rnd("do", b, C, h, w)
+    qr, tr = qkv.clone().requires_grad_(True), temp.clone().requires_grad_(True)
+    q, k, v = (s.reshape(b, heads, c, h * w) for s in qr.split(C, dim=1))
+    qn, kn = F.normalize(q, dim=-1), F.normalize(k, dim=-1)
+    out = (torch.softmax(qn @ kn.transpose(-1, -2) * tr, dim=-1) @ v).reshape(b, C, h, w)
+    out.backward(dout)
+    og, attn, gram, sumsq = ops.mdta_core_forward(qkv.to(DEV), temp.to(DEV), heads)
+    close(og, out.detach())
+    dqkv, dtemp = ops.mdta_core_backward(dout.to(DEV), qkv.to(DEV), temp.to(DEV), heads, attn, gram, sumsq)
+    close(dqkv, qr.grad, rtol=1e-4)
+    close(dtemp, tr.grad, rtol=1e-4)
+
+
+def test_gemm_nt_determinism_and_linearity():
+    """Size-independent properties at a BASELINE-sized contraction (batch 8, 128x128 pixels)."""
+    from promptir_amd import ops
+
+    dy, x = rnd("dy", 8, 48, 128, 128).to(DEV), rnd("x", 8, 48, 128, 128).to(DEV)
+    like = torch.empty(48, 48, 1, 1, device=DEV)
+    a = ops.conv1x1_wgrad(dy, x, like)
+    b = ops.conv1x1_wgrad(dy, x, like)
+    assert torch.equal(a, b)                                          # split-K reduction is order-fixed
+    c = ops.conv1x1_wgrad(dy * 2, x, like)
+    assert float((c - 2 * a).abs().max()) == 0.0                      # exact: scaling by 2 commutes with fp32 rounding
+    ref = torch.einsum("bmn,bkn->mk", dy.cpu().double().flatten(2), x.cpu().double().flatten(2))
+    assert float((a.cpu().double().view(48, 48) - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+def test_l1_and_adamw():
+    from promptir_amd import ops
+
+    a, b = rnd("a", 2, 3, 16, 16), rnd("b", 2, 3, 16, 16)
+    ar = a.clone().requires_grad_(True)
+    ref = (ar - b).abs().mean()
+    ref.backward()
+    ag = a.to(DEV).requires_grad_(True)
+    loss = ops.l1_loss(ag, b.to(DEV))
+    loss.backward()
+    assert abs(float(loss) - float(ref.detach())) <= 1e-7
+    assert torch.equal(ag.grad.cpu(), ar.grad)
+
+    p, g = rnd("p", 1000), rnd("g", 1000)
+    pr = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([pr], lr=2e-4)
+    pg, m, v = p.to(DEV), torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV)
+    for step in range(1, 4):
+        pr.grad = g.clone() * step
+        opt.step()
+        ops.adamw_step(pg, (g * step).to(DEV), m, v, step)
+    assert float((pg.cpu() - pr.detach()).abs().max()) <= 1e-7
