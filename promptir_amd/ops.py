@@ -16,7 +16,60 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import lib, check
+from ._lib import check
+
+
+class _TimedLib:
+    """Pass-through to the C ABI.  With `start_timing()` every entry point is bracketed by HIP
+    events recorded on the stream the kernels are launched on (torch's current stream), which
+    is how bench.py measures per-kernel launch durations live."""
+
+    def __init__(self, raw):
+        self._raw = raw
+        self.records = None
+
+    def start_timing(self):
+        self.records = []
+
+    def stop_timing(self):
+        recs, self.records = self.records, None
+        torch.cuda.synchronize()
+        out = []
+        for name, start, end, work in recs:
+            out.append((name, start.elapsed_time(end) * 1e-3, work))
+        return out
+
+    @staticmethod
+    def _work(name, args):
+        """Algorithmic FLOPs of one call for the MFMA families (0 for the streaming kernels)."""
+        if name == "pir_gemm_nn":
+            g = args[0]._obj
+            return 2.0 * g.M * g.K * g.N * g.O1 * g.O2
+        if name == "pir_gemm_nt":
+            g = args[0]._obj
+            return 2.0 * g.M1 * g.M2 * g.N * g.O1 * g.O2 * g.BR
+        if name == "pir_conv3x3":
+            b, m, k, h, w = args[11:16]
+            return 2.0 * 9 * m * k * h * w * b
+        return 0.0
+
+    def __getattr__(self, name):
+        fn = getattr(self._raw, name)
+        if self.records is None or name.endswith("_ws_floats"):
+            return fn
+
+        def timed(*args):
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record()
+            status = fn(*args)
+            end.record()
+            self.records.append((name, start, end, self._work(name, args)))
+            return status
+
+        return timed
+
+
+lib = _TimedLib(_lib.lib)
 
 
 # ----------------------------------------------------------------------------- plumbing
@@ -136,13 +189,17 @@ def conv1x1_dgrad(dy: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor]
     return out
 
 
-def conv1x1_wgrad(dy: torch.Tensor, x: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+def _grad_out(like: torch.Tensor, out: Optional[torch.Tensor]) -> torch.Tensor:
+    return out if out is not None else torch.empty_like(like, memory_format=torch.contiguous_format)
+
+
+def conv1x1_wgrad(dy: torch.Tensor, x: torch.Tensor, like: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dW = sum_b dy[b] x[b]^T, shaped like the weight."""
     dy, x = _planes(dy), _planes(x)
     b, cout, h, wd = dy.shape
     cin = x.shape[1]
     hw = h * wd
-    dw = torch.empty_like(like, memory_format=torch.contiguous_format)
+    dw = _grad_out(like, out)
     gemm_nt(dy, 0, (0, 0, _bs(dy)), hw, x, 0, (0, 0, _bs(x)), hw, dw, 0, (0, cin, 1), cout, cin, hw, 1, 1, b)
     return dw
 
@@ -171,12 +228,12 @@ def conv3x3_dgrad(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def conv3x3_wgrad(dy: torch.Tensor, x: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+def conv3x3_wgrad(dy: torch.Tensor, x: torch.Tensor, like: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     dy, x = _planes(dy), _planes(x)
     b, cout, h, wd = dy.shape
     cin = x.shape[1]
     hw = h * wd
-    dw = torch.empty_like(like, memory_format=torch.contiguous_format)
+    dw = _grad_out(like, out)
     for tap in range(9):
         gemm_nt(dy, 0, (0, 0, _bs(dy)), hw, x, 0, (0, 0, _bs(x)), hw, dw, tap, (0, cin * 9, 9),
                 cout, cin, hw, 1, 1, b, shift=(tap // 3 - 1, tap % 3 - 1, h, wd))
@@ -194,12 +251,12 @@ def layernorm_forward(x, weight, bias):
     return y, mean, rstd
 
 
-def layernorm_backward(dy, x, weight, with_bias, mean, rstd):
+def layernorm_backward(dy, x, weight, with_bias, mean, rstd, dweight=None, dbias=None):
     dy, x = _planes(dy), _planes(x)
     b, c, h, w = x.shape
     dx = torch.empty((b, c, h, w), dtype=torch.float32, device=x.device)
-    dweight = torch.empty_like(weight)
-    dbias = torch.empty_like(weight) if with_bias else None
+    dweight = _grad_out(weight, dweight)
+    dbias = _grad_out(weight, dbias) if with_bias else None
     nws = lib.pir_layernorm_bwd_ws_floats(b, c, h * w)
     ws = workspace(nws, x.device)
     check(lib.pir_layernorm_bwd(dy.data_ptr(), _bs(dy), x.data_ptr(), _bs(x), weight.data_ptr(), int(with_bias),
@@ -218,10 +275,10 @@ def dwconv_forward(x, w, flip=False, out=None):
     return out
 
 
-def dwconv_wgrad(dy, x, like):
+def dwconv_wgrad(dy, x, like, out=None):
     dy, x = _planes(dy), _planes(x)
     b, c, h, wd = x.shape
-    dw = torch.empty_like(like, memory_format=torch.contiguous_format)
+    dw = _grad_out(like, out)
     nws = lib.pir_dwconv3x3_wgrad_ws_floats(b, c, h, wd)
     ws = workspace(nws, x.device)
     check(lib.pir_dwconv3x3_wgrad(dy.data_ptr(), _bs(dy), x.data_ptr(), _bs(x), dw.data_ptr(), ws.data_ptr(),
@@ -286,7 +343,7 @@ def mdta_core_forward(qkv: torch.Tensor, temperature: torch.Tensor, heads: int):
     return out, attn, gram, sumsq
 
 
-def mdta_core_backward(dout, qkv, temperature, heads, attn, gram, sumsq):
+def mdta_core_backward(dout, qkv, temperature, heads, attn, gram, sumsq, dtemp_out=None):
     dout, qkv = _planes(dout), _planes(qkv)
     b, c3, h, w = qkv.shape
     c_all = c3 // 3
@@ -318,7 +375,7 @@ def mdta_core_backward(dout, qkv, temperature, heads, attn, gram, sumsq):
     gemm_nn(dgram, (heads * c * c, c * c), 1, c, qkv, 0, (bs, c * hw), hw,
             dqkv, c_all * hw, (qbs, c * hw), hw, c, c, hw, b, heads,
             R=qkv, r_off=c_all * hw, r_batch=(bs, c * hw), ldr=hw, rowscale=alpha_k, rs_batch=(c_all, c))
-    dtemp = torch.empty_like(temperature)
+    dtemp = _grad_out(temperature, dtemp_out)
     reduce_partials(dtemp_part, heads, b, dtemp, heads)
     return dqkv, dtemp
 
@@ -346,20 +403,33 @@ def pixel_shuffle(x):
 
 
 # ----------------------------------------------------------------------------- autograd Functions
+# Gradient sinks: when a Parameter carries `_grad_sink` (a view into the training engine's flat
+# gradient buffer, promptir_amd/train.py) the weight-gradient kernel writes straight into it and the
+# Function returns None for that input, so autograd launches no accumulation kernel of its own.
+def _sink(p):
+    return getattr(p, "_grad_sink", None) if p is not None else None
+
+
+def _ret(grad, sink):
+    return None if sink is not None else grad
+
+
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         _require_gpu(x, weight, bias)
         y, mean, rstd = layernorm_forward(x, weight, bias)
         ctx.with_bias = bias is not None
+        ctx.sinks = (_sink(weight), _sink(bias))
         ctx.save_for_backward(x, weight, mean, rstd)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight, mean, rstd = ctx.saved_tensors
-        dx, dw, db = layernorm_backward(dy, x, weight, ctx.with_bias, mean, rstd)
-        return dx, dw, db
+        sw, sb = ctx.sinks
+        dx, dw, db = layernorm_backward(dy, x, weight, ctx.with_bias, mean, rstd, sw, sb)
+        return dx, _ret(dw, sw), _ret(db, sb)
 
 
 class Conv1x1Fn(torch.autograd.Function):
@@ -370,14 +440,15 @@ class Conv1x1Fn(torch.autograd.Function):
         _require_gpu(x, w, residual)
         ctx.save_for_backward(x, w)
         ctx.has_res = residual is not None
+        ctx.sink = _sink(w)
         return conv1x1_forward(x, w, residual)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dx = conv1x1_dgrad(dy, w) if ctx.needs_input_grad[0] else None
-        dw = conv1x1_wgrad(dy, x, w) if ctx.needs_input_grad[1] else None
-        return dx, dw, (dy if ctx.has_res and ctx.needs_input_grad[2] else None)
+        dw = conv1x1_wgrad(dy, x, w, ctx.sink) if ctx.needs_input_grad[1] else None
+        return dx, _ret(dw, ctx.sink), (dy if ctx.has_res and ctx.needs_input_grad[2] else None)
 
 
 class Conv3x3Fn(torch.autograd.Function):
@@ -386,14 +457,15 @@ class Conv3x3Fn(torch.autograd.Function):
         _require_gpu(x, w, residual)
         ctx.save_for_backward(x, w)
         ctx.has_res = residual is not None
+        ctx.sink = _sink(w)
         return conv3x3_forward(x, w, residual)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dx = conv3x3_dgrad(dy, w) if ctx.needs_input_grad[0] else None
-        dw = conv3x3_wgrad(dy, x, w) if ctx.needs_input_grad[1] else None
-        return dx, dw, (dy if ctx.has_res and ctx.needs_input_grad[2] else None)
+        dw = conv3x3_wgrad(dy, x, w, ctx.sink) if ctx.needs_input_grad[1] else None
+        return dx, _ret(dw, ctx.sink), (dy if ctx.has_res and ctx.needs_input_grad[2] else None)
 
 
 class DwConvFn(torch.autograd.Function):
@@ -401,14 +473,15 @@ class DwConvFn(torch.autograd.Function):
     def forward(ctx, x, w):
         _require_gpu(x, w)
         ctx.save_for_backward(x, w)
+        ctx.sink = _sink(w)
         return dwconv_forward(x, w)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dx = dwconv_forward(dy, w, flip=True) if ctx.needs_input_grad[0] else None
-        dw = dwconv_wgrad(dy, x, w) if ctx.needs_input_grad[1] else None
-        return dx, dw
+        dw = dwconv_wgrad(dy, x, w, ctx.sink) if ctx.needs_input_grad[1] else None
+        return dx, _ret(dw, ctx.sink)
 
 
 class DwConvGateFn(torch.autograd.Function):
@@ -418,6 +491,7 @@ class DwConvGateFn(torch.autograd.Function):
     def forward(ctx, x, w):
         _require_gpu(x, w)
         ctx.save_for_backward(x, w)
+        ctx.sink = _sink(w)
         return dwconv_gate_forward(x, w)
 
     @staticmethod
@@ -425,8 +499,8 @@ class DwConvGateFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dt = dwconv_gate_backward(x, w, dg)
         dx = dwconv_forward(dt, w, flip=True) if ctx.needs_input_grad[0] else None
-        dw = dwconv_wgrad(dt, x, w) if ctx.needs_input_grad[1] else None
-        return dx, dw
+        dw = dwconv_wgrad(dt, x, w, ctx.sink) if ctx.needs_input_grad[1] else None
+        return dx, _ret(dw, ctx.sink)
 
 
 class MdtaCoreFn(torch.autograd.Function):
@@ -435,14 +509,15 @@ class MdtaCoreFn(torch.autograd.Function):
         _require_gpu(qkv, temperature)
         out, attn, gram, sumsq = mdta_core_forward(qkv, temperature, heads)
         ctx.heads = heads
+        ctx.sink = _sink(temperature)
         ctx.save_for_backward(qkv, temperature, attn, gram, sumsq)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, temperature, attn, gram, sumsq = ctx.saved_tensors
-        dqkv, dtemp = mdta_core_backward(dout, qkv, temperature, ctx.heads, attn, gram, sumsq)
-        return dqkv, dtemp, None
+        dqkv, dtemp = mdta_core_backward(dout, qkv, temperature, ctx.heads, attn, gram, sumsq, ctx.sink)
+        return dqkv, _ret(dtemp, ctx.sink), None
 
 
 class PixelUnshuffleFn(torch.autograd.Function):
@@ -505,6 +580,7 @@ class PromptGenFn(torch.autograd.Function):
                                         b, L, D, S, h, w, _stream()), "pir_prompt_resize_fwd")
         ctx.save_for_backward(emb, mix, prompt_param, lin_w)
         ctx.x_shape = (b, c, h, w)
+        ctx.sinks = (_sink(prompt_param), _sink(lin_w), _sink(lin_b))
         return out
 
     @staticmethod
@@ -514,20 +590,21 @@ class PromptGenFn(torch.autograd.Function):
         b, c, h, w = ctx.x_shape
         _, L, D, S, _ = prompt_param.shape
         dev = dout.device
-        dP = torch.empty_like(prompt_param)
+        sP, sW, sB = ctx.sinks
+        dP = _grad_out(prompt_param, sP)
         dmix = torch.empty_like(mix)
         nws = lib.pir_prompt_resize_bwd_ws_floats(b, L, D, S, h, w)
         ws = workspace(nws, dev)
         check(lib.pir_prompt_resize_bwd(dout.data_ptr(), _bs(dout), mix.data_ptr(), prompt_param.data_ptr(),
                                         dP.data_ptr(), dmix.data_ptr(), ws.data_ptr(), ws.numel(),
                                         b, L, D, S, h, w, _stream()), "pir_prompt_resize_bwd")
-        dWl = torch.empty_like(lin_w)
-        dbl = torch.empty((L,), dtype=torch.float32, device=dev)
+        dWl = _grad_out(lin_w, sW)
+        dbl = sB if sB is not None else torch.empty((L,), dtype=torch.float32, device=dev)
         dx = torch.empty((b, c, h, w), dtype=torch.float32, device=dev)
         check(lib.pir_prompt_mix_bwd(dmix.data_ptr(), mix.data_ptr(), emb.data_ptr(), lin_w.data_ptr(),
                                      dWl.data_ptr(), dbl.data_ptr(), dx.data_ptr(), _bs(dx), 0, b, c, L, h * w,
                                      _stream()), "pir_prompt_mix_bwd")
-        return dx, dP, dWl, dbl
+        return dx, _ret(dP, sP), _ret(dWl, sW), _ret(dbl, sB)
 
 
 class L1LossFn(torch.autograd.Function):

@@ -166,7 +166,7 @@ def test_l1_and_adamw():
     ag = a.to(DEV).requires_grad_(True)
     loss = ops.l1_loss(ag, b.to(DEV))
     loss.backward()
-    assert abs(float(loss) - float(ref.detach())) <= 1e-7
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-7
     assert torch.equal(ag.grad.cpu(), ar.grad)
 
     p, g = rnd("p", 1000), rnd("g", 1000)
