@@ -158,7 +158,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_kernel(NNParams p) {
     __syncthreads();
   }
 
-  // epilogue: each store instruction writes two 128-byte row segments
+  // epilogue: each store instruction writes two 128-byte row segments.  Residual loads of one
+  // 32x32 tile are issued back-to-back from clamped (always in-bounds) addresses so they overlap;
+  // a guarded load->add->store chain per element would serialise on HBM latency.
   const float* __restrict__ R = g.R ? g.R + o1 * g.r_s1 + o2 * g.r_s2 : nullptr;
   const float* __restrict__ RS = g.rowscale ? g.rowscale + o1 * g.rs_s1 + o2 * g.rs_s2 : nullptr;
 #pragma unroll
@@ -166,14 +168,28 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_kernel(NNParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+      const int mb = m0 + (wm * TM + i) * 32;
+      const int nc = n < g.N ? n : g.N - 1;
+      float res[16];
+      if (R) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + c_row(r, lane);
+          const int mc = m < g.M ? m : g.M - 1;
+          res[r] = R[(long)mc * g.ldr + nc];
+        }
+        if (RS) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = mb + c_row(r, lane);
+            res[r] *= RS[m < g.M ? m : g.M - 1];
+          }
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * TM + i) * 32 + c_row(r, lane);
-        if (m < g.M && n < g.N) {
-          float v = acc[i][j][r];
-          if (R) v += (RS ? RS[m] : 1.f) * R[(long)m * g.ldr + n];
-          Y[(long)m * g.ldy + n] = v;
-        }
+        const int m = mb + c_row(r, lane);
+        if (m < g.M && n < g.N) Y[(long)m * g.ldy + n] = R ? acc[i][j][r] + res[r] : acc[i][j][r];
       }
     }
 }
@@ -218,17 +234,19 @@ constexpr int NT_BK = 32;  // pixels per LDS stage
 
 struct NTParams {
   pir_gemm_nt_t g;
-  int splits;       // split-K factor over the flattened (r, n-chunk) axis
-  int chunks_per_r; // ceil(N / NT_BK)
+  int splits;        // split-K factor over the flattened (r, n-chunk) axis
+  int chunks_per_r;  // ceil(N / NT_BK)
 };
 
-// WK waves of a block share an output tile and each takes a quarter of every stage's k-range.
-template <int TM, int TN, int WM, int WN, int WK>
+// WK waves of a block share an output tile and each takes a slice of every stage's k-range.
+// VEC=4: 16-byte loads along the pixel axis (needs 16-byte aligned rows), transposed into the
+// k-major LDS image by four conflict-free ds_write_b32 (odd row stride).
+template <int TM, int TN, int WM, int WN, int WK, int VEC>
 __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_nt_kernel(NTParams p) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, T = WM * WN * WK * 64;
   constexpr int XS = BM + 1, YS = BN + 1;  // odd strides: conflict-free transposing stores
   constexpr int STAGE = NT_BK * (XS + YS);
-  constexpr int RED = (WK > 1) ? (WK - 1) * TM * TN * 16 * 64 : 0;
+  constexpr int RED = (WK > 1) ? WM * WN * (WK / 2) * TM * TN * 16 * 64 : 0;  // pairwise tree: half the waves park
   constexpr int SMEM = (2 * STAGE > RED) ? 2 * STAGE : RED;
   __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
@@ -243,14 +261,14 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_nt_kernel(NTParams p) {
   const float* __restrict__ Xb = g.X + o1 * g.x_s1 + o2 * g.x_s2;
   const float* __restrict__ Yb = g.Y + o1 * g.y_s1 + o2 * g.y_s2;
 
-  // this block's slice of the flattened (r, chunk) axis
   const long total = (long)g.BR * p.chunks_per_r;
   const long per = (total + p.splits - 1) / p.splits;
   const long c_begin = split * per, c_end = (c_begin + per < total) ? c_begin + per : total;
 
-  constexpr int X_EL = NT_BK * BM, NX = (X_EL + T - 1) / T;
-  constexpr int Y_EL = NT_BK * BN, NY = (Y_EL + T - 1) / T;
-  float rx[NX], ry[NY];
+  constexpr int CPR = NT_BK / VEC;                       // vector chunks per row of a stage
+  constexpr int X_CH = CPR * BM, NX = (X_CH + T - 1) / T;
+  constexpr int Y_CH = CPR * BN, NY = (Y_CH + T - 1) / T;
+  float rx[NX][VEC], ry[NY][VEC];
 
   auto load = [&](long c) {
     const int r = (int)(c / p.chunks_per_r);
@@ -260,23 +278,37 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_nt_kernel(NTParams p) {
 #pragma unroll
     for (int q = 0; q < NX; ++q) {
       const int e = tid + q * T;
-      const int nn = e % NT_BK, ii = e / NT_BK;
+      const int nn = (e % CPR) * VEC, ii = e / CPR;
       const int n = nb + nn, i = i0 + ii;
-      rx[q] = ((X_EL % T == 0 || e < X_EL) && n < g.N && i < g.M1) ? Xp[(long)i * g.ldx + n] : 0.f;
+      const bool ok = (X_CH % T == 0 || e < X_CH) && i < g.M1;
+      if (VEC == 4) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok && n < g.N) v = *reinterpret_cast<const f32x4*>(Xp + (long)i * g.ldx + n);
+        rx[q][0] = v[0]; rx[q][1] = v[1]; rx[q][2] = v[2]; rx[q][3] = v[3];
+      } else {
+        rx[q][0] = (ok && n < g.N) ? Xp[(long)i * g.ldx + n] : 0.f;
+      }
     }
 #pragma unroll
     for (int q = 0; q < NY; ++q) {
       const int e = tid + q * T;
-      const int nn = e % NT_BK, jj = e / NT_BK;
+      const int nn = (e % CPR) * VEC, jj = e / CPR;
       const int n = nb + nn, j = j0 + jj;
-      bool ok = (Y_EL % T == 0 || e < Y_EL) && n < g.N && j < g.M2;
-      long off = (long)j * g.ldy + n;
-      if (g.H > 0) {  // 3x3 tap shift on the Y operand (dense 3x3 weight gradient)
-        const int h = n / g.W + g.shift_dh, w = n % g.W + g.shift_dw;
-        ok = ok && h >= 0 && h < g.H && w >= 0 && w < g.W;
-        off = (long)j * g.ldy + (long)h * g.W + w;
+      const bool ok = (Y_CH % T == 0 || e < Y_CH) && j < g.M2;
+      if (VEC == 4) {  // never used with a tap shift (launcher picks VEC=1 then)
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok && n < g.N) v = *reinterpret_cast<const f32x4*>(Yp + (long)j * g.ldy + n);
+        ry[q][0] = v[0]; ry[q][1] = v[1]; ry[q][2] = v[2]; ry[q][3] = v[3];
+      } else {
+        bool okn = ok && n < g.N;
+        long off = (long)j * g.ldy + n;
+        if (g.H > 0) {  // 3x3 tap shift on the Y operand (dense 3x3 weight gradient)
+          const int h = n / g.W + g.shift_dh, w = n % g.W + g.shift_dw;
+          okn = okn && h >= 0 && h < g.H && w >= 0 && w < g.W;
+          off = (long)j * g.ldy + (long)h * g.W + w;
+        }
+        ry[q][0] = okn ? Yp[off] : 0.f;
       }
-      ry[q] = ok ? Yp[off] : 0.f;
     }
   };
   auto stash = [&](int buf) {
@@ -285,12 +317,18 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_nt_kernel(NTParams p) {
 #pragma unroll
     for (int q = 0; q < NX; ++q) {
       const int e = tid + q * T;
-      if (X_EL % T == 0 || e < X_EL) Xs[(e % NT_BK) * XS + e / NT_BK] = rx[q];
+      if (X_CH % T == 0 || e < X_CH) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) Xs[((e % CPR) * VEC + v) * XS + e / CPR] = rx[q][v];
+      }
     }
 #pragma unroll
     for (int q = 0; q < NY; ++q) {
       const int e = tid + q * T;
-      if (Y_EL % T == 0 || e < Y_EL) Ys[(e % NT_BK) * YS + e / NT_BK] = ry[q];
+      if (Y_CH % T == 0 || e < Y_CH) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) Ys[((e % CPR) * VEC + v) * YS + e / CPR] = ry[q][v];
+      }
     }
   };
 
@@ -330,23 +368,23 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_nt_kernel(NTParams p) {
     }
   }
 
-  // cross-wave (WK) reduction through LDS, fixed order -> deterministic
+  // cross-wave (WK) reduction: pairwise tree through LDS, fixed order -> deterministic
   if (WK > 1) {
-    __syncthreads();
-    if (wk > 0) {
-      float* dst = smem + ((wk - 1) * TM * TN * 16) * 64;
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+    for (int half = WK / 2; half >= 1; half >>= 1) {
+      __syncthreads();
+      if (wk >= half && wk < 2 * half) {
+        float* dst = smem + ((wmn * half + (wk - half)) * TM * TN * 16) * 64;
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) dst[((i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
-    }
-    __syncthreads();
-    if (wk == 0) {
-#pragma unroll 1
-      for (int w = 1; w < WK; ++w) {
-        const float* src = smem + ((w - 1) * TM * TN * 16) * 64;
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[((i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+      }
+      __syncthreads();
+      if (wk < half) {
+        const float* src = smem + ((wmn * half + wk) * TM * TN * 16) * 64;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -373,13 +411,33 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_nt_kernel(NTParams p) {
     }
 }
 
-// G[o][i][j] (strided) = alpha * sum_s ws[s][o][i][j]  (+ G)
-__global__ void nt_reduce_kernel(const float* __restrict__ ws, int splits, long per_split, int M1, int M2,
-                                 float* __restrict__ G, long g_so, long g_si, long g_sj, long total,
-                                 float alpha, int accumulate) {
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+// G[o][i][j] (strided) = alpha * sum_s ws[s][o][i][j]  (+ G).  64 consecutive elements x GR split
+// groups per block; every thread sums its groups' splits with independent loads in flight, the
+// groups are combined through LDS in a fixed order (deterministic).
+template <int GR>
+__global__ __launch_bounds__(64 * GR) void nt_reduce_kernel(const float* __restrict__ ws, int splits, long per_split,
+                                                            int M1, int M2, float* __restrict__ G, long g_so,
+                                                            long g_si, long g_sj, float alpha, int accumulate) {
+  __shared__ float red[GR][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long e = blockIdx.x * 64L + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < per_split) {
+    int k = grp;
+    for (; k + 3 * GR < splits; k += 4 * GR) {
+      s0 += ws[(long)k * per_split + e];
+      s1 += ws[(long)(k + GR) * per_split + e];
+      s2 += ws[(long)(k + 2 * GR) * per_split + e];
+      s3 += ws[(long)(k + 3 * GR) * per_split + e];
+    }
+    for (; k < splits; k += GR) s0 += ws[(long)k * per_split + e];
+  }
+  red[grp][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0 && e < per_split) {
     float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += ws[k * per_split + e];
+#pragma unroll
+    for (int q = 0; q < GR; ++q) s += red[q][lane];
     const long o = e / ((long)M1 * M2);
     const long ij = e % ((long)M1 * M2);
     const long i = ij / M2, j = ij % M2;
@@ -389,25 +447,36 @@ __global__ void nt_reduce_kernel(const float* __restrict__ ws, int splits, long 
   }
 }
 
+// tile configurations of gemm_nt: 0: 64x64 (4 k-slices)  1: 128x64 (2 k-slices)  2: 128x96 (2 k-slices)  3: 128x128
 struct NTPlan {
-  bool small;
+  int cfg, bm, bn;
   int splits, chunks_per_r;
 };
 
 NTPlan nt_plan(int M1, int M2, int N, int O, int BR) {
   NTPlan pl;
-  pl.small = (long)M1 * M2 <= 96L * 96L || M1 <= 64 || M2 <= 64;
-  const int bm = pl.small ? 64 : 128;
-  const long tiles = pir_cdiv(M1, bm) * pir_cdiv(M2, bm) * O;
+  if (M1 <= 64 && M2 <= 64) { pl.cfg = 0; pl.bm = 64; pl.bn = 64; }
+  else if (M2 <= 64) { pl.cfg = 1; pl.bm = 128; pl.bn = 64; }
+  else {
+    const long pad96 = pir_cdiv(M2, 96) * 96, pad128 = pir_cdiv(M2, 128) * 128;
+    if (pad96 < pad128) { pl.cfg = 2; pl.bm = 128; pl.bn = 96; } else { pl.cfg = 3; pl.bm = 128; pl.bn = 128; }
+  }
+  const long tiles = pir_cdiv(M1, pl.bm) * pir_cdiv(M2, pl.bn) * O;
   pl.chunks_per_r = (int)pir_cdiv(N, NT_BK);
   const long total = (long)BR * pl.chunks_per_r;
-  long want = pir_cdiv(4L * PIR_NUM_CU, tiles);        // ~4 blocks per CU overall
-  long max_by_work = total / 8 > 0 ? total / 8 : 1;      // at least 8 stages (256 pixels) per split
+  long want = pir_cdiv(3L * PIR_NUM_CU, tiles);          // ~3 blocks per CU overall
+  long max_by_work = total / 16 > 0 ? total / 16 : 1;     // at least 16 stages (512 pixels) per split
   long s = want < max_by_work ? want : max_by_work;
   if (s < 1) s = 1;
   if (s > 1024) s = 1024;
   pl.splits = (int)s;
   return pl;
+}
+
+template <int TM, int TN, int WM, int WN, int WK>
+void launch_nt_cfg(const NTParams& p, dim3 grid, bool vec4, hipStream_t s) {
+  if (vec4) hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, WK, 4>), grid, dim3(WM * WN * WK * 64), 0, s, p);
+  else hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, WK, 1>), grid, dim3(WM * WN * WK * 64), 0, s, p);
 }
 
 }  // namespace
@@ -442,8 +511,10 @@ extern "C" int pir_conv3x3(const float* A, long a_st, long a_sm, long a_sk, int 
 
 extern "C" size_t pir_gemm_nt_ws_floats(int M1, int M2, int N, int O, int BR) {
   if (M1 <= 0 || M2 <= 0 || N <= 0 || O <= 0 || BR <= 0) return 0;
-  NTPlan pl = nt_plan(M1, M2, N, O, BR);
-  return (size_t)pl.splits * O * M1 * M2;
+  // the launcher may swap the operands so that the larger extent plays M1: size for the worst of both
+  NTPlan a = nt_plan(M1, M2, N, O, BR), b = nt_plan(M2, M1, N, O, BR);
+  const int s = a.splits > b.splits ? a.splits : b.splits;
+  return (size_t)s * O * M1 * M2;
 }
 
 extern "C" int pir_gemm_nt(const pir_gemm_nt_t* a, pir_stream_t stream) {
@@ -452,25 +523,47 @@ extern "C" int pir_gemm_nt(const pir_gemm_nt_t* a, pir_stream_t stream) {
   const int O = a->O1 * a->O2;
   PIR_CHECK_ARG(O <= 65535);
   PIR_CHECK_ARG(a->H == 0 || (long)a->H * a->W == a->N);
-  NTPlan pl = nt_plan(a->M1, a->M2, a->N, O, a->BR);
-  if ((size_t)pl.splits * O * a->M1 * a->M2 > a->ws_floats) return PIR_ENOMEM;
   NTParams p;
   p.g = *a;
+  pir_gemm_nt_t& g = p.g;
+  // G^T[j][i] = sum_n Y[j][n] X[i][n]: the output strides are free, so put the larger extent on M1
+  // (tile rows) unless a tap shift pins the second operand.
+  if (g.H == 0 && g.M2 > g.M1) {
+    const float* t = g.X; g.X = g.Y; g.Y = t;
+    long v;
+    v = g.x_s1; g.x_s1 = g.y_s1; g.y_s1 = v;
+    v = g.x_s2; g.x_s2 = g.y_s2; g.y_s2 = v;
+    v = g.x_sr; g.x_sr = g.y_sr; g.y_sr = v;
+    v = g.ldx; g.ldx = g.ldy; g.ldy = v;
+    v = g.g_si; g.g_si = g.g_sj; g.g_sj = v;
+    int m = g.M1; g.M1 = g.M2; g.M2 = m;
+  }
+  NTPlan pl = nt_plan(g.M1, g.M2, g.N, O, g.BR);
+  if ((size_t)pl.splits * O * g.M1 * g.M2 > a->ws_floats) return PIR_ENOMEM;
   p.splits = pl.splits;
   p.chunks_per_r = pl.chunks_per_r;
   hipStream_t s = (hipStream_t)stream;
-  if (pl.small) {
-    dim3 grid((unsigned)(pir_cdiv(a->M1, 64) * pir_cdiv(a->M2, 64)), (unsigned)pl.splits, (unsigned)O);
-    hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 1, 1, 4>), grid, dim3(256), 0, s, p);
-  } else {
-    dim3 grid((unsigned)(pir_cdiv(a->M1, 128) * pir_cdiv(a->M2, 128)), (unsigned)pl.splits, (unsigned)O);
-    hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 2, 2, 1>), grid, dim3(256), 0, s, p);
+  auto al = [](const float* q, long s1, long s2, long sr, long ld) {
+    return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && s1 % 4 == 0 && s2 % 4 == 0 && sr % 4 == 0 && ld % 4 == 0;
+  };
+  const bool vec4 = g.H == 0 && g.N % 4 == 0 && al(g.X, g.x_s1, g.x_s2, g.x_sr, g.ldx) &&
+                    al(g.Y, g.y_s1, g.y_s2, g.y_sr, g.ldy);
+  dim3 grid((unsigned)(pir_cdiv(g.M1, pl.bm) * pir_cdiv(g.M2, pl.bn)), (unsigned)pl.splits, (unsigned)O);
+  switch (pl.cfg) {
+    case 0: launch_nt_cfg<2, 2, 1, 1, 4>(p, grid, vec4, s); break;
+    case 1: launch_nt_cfg<2, 2, 2, 1, 2>(p, grid, vec4, s); break;
+    case 2: launch_nt_cfg<2, 3, 2, 1, 2>(p, grid, vec4, s); break;
+    default: launch_nt_cfg<2, 2, 2, 2, 1>(p, grid, vec4, s); break;
   }
   int st = pir_launch_status();
   if (st) return st;
-  const long per_split = (long)O * a->M1 * a->M2;
-  const int blocks = (int)(pir_cdiv(per_split, 256) < 2048 ? pir_cdiv(per_split, 256) : 2048);
-  hipLaunchKernelGGL(nt_reduce_kernel, dim3(blocks), dim3(256), 0, s, a->ws, pl.splits, per_split, a->M1, a->M2,
-                     a->G, a->g_so, a->g_si, a->g_sj, per_split, a->alpha, a->accumulate);
+  const long per_split = (long)O * g.M1 * g.M2;
+  const unsigned blocks = (unsigned)pir_cdiv(per_split, 64);
+  if (pl.splits >= 64)
+    hipLaunchKernelGGL((nt_reduce_kernel<16>), dim3(blocks), dim3(1024), 0, s, a->ws, pl.splits, per_split, g.M1, g.M2,
+                       g.G, g.g_so, g.g_si, g.g_sj, g.alpha, g.accumulate);
+  else
+    hipLaunchKernelGGL((nt_reduce_kernel<4>), dim3(blocks), dim3(256), 0, s, a->ws, pl.splits, per_split, g.M1, g.M2,
+                       g.G, g.g_so, g.g_si, g.g_sj, g.alpha, g.accumulate);
   return pir_launch_status();
 }
