@@ -12,10 +12,15 @@
 // Operand lane maps (cdna_hip_programming.md §3): A: lane l holds A[i=l&31][k=l>>5],
 // B: B[k=l>>5][j=l&31]; C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 #include "pir_common.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int BK = 16;  // k-depth of one LDS stage (8 MFMA k-steps)
+#ifndef PIR_PIN_SCHED
+#define PIR_PIN_SCHED 0  /* A/B on MI355X: pinning the ds_read/MFMA order is 1.5% slower overall */
+#endif
+constexpr bool PIN_SCHED = PIR_PIN_SCHED;
 
 __device__ __forceinline__ int c_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
@@ -29,7 +34,13 @@ struct NNParams {
   long a_st;
 };
 
-template <int TM, int TN, int WM, int WN, bool A_MFAST, int VEC, bool CONV>
+template <int NA, int NB, int VEC>
+struct NNStage {  // one k-stage of both operands held in registers between global load and LDS store
+  float a[NA];
+  float b[NB][VEC];
+};
+
+template <int TM, int TN, int WM, int WN, bool A_MFAST, int VEC, bool CONV, int DEPTH>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_kernel(NNParams p) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, T = WM * WN * 64;
   constexpr int AS = BM + 2;  // LDS row strides (floats); +2 keeps the k-fast A staging conflict-free
@@ -51,25 +62,29 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_kernel(NNParams p) {
 
   constexpr int A_EL = BK * BM, NA = (A_EL + T - 1) / T;
   constexpr int B_CH = BK * BN / VEC, NB = (B_CH + T - 1) / T;
-  float ra[NA];
-  float rb[NB][VEC];
+  using Stage = NNStage<NA, NB, VEC>;
 
   const int ktiles = (g.K + BK - 1) / BK;
   const int iters = ktiles * (CONV ? 9 : 1);
 
-  auto load = [&](int it) {
+  // Loads are unconditional from clamped (always valid) addresses: no exec-mask branches, and
+  // nothing consumes the values until stash(), so the loads stay in flight across compute().
+  // Out-of-range elements are zeroed when the stage is written to LDS (stash recomputes the
+  // predicates).  Addresses are (wave-uniform stage base) + (32-bit per-thread offset).
+  auto load = [&](int it, Stage& st) {
     const int tap = CONV ? it / ktiles : 0;
     const int k0 = (CONV ? it % ktiles : it) * BK;
-    const float* At = A + (CONV ? (long)(p.flip ? 8 - tap : tap) * p.a_st : 0);
+    const int klast = g.K - 1 - k0;  // last valid k offset inside this stage (>= 0)
+    const float* __restrict__ At = A + (CONV ? (long)(p.flip ? 8 - tap : tap) * p.a_st : 0) + (long)k0 * g.a_sk;
+    const float* __restrict__ Xt = X + (long)k0 * g.ldx;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + i * T;
       int kk, mm;
       if (A_MFAST) { mm = e % BM; kk = e / BM; } else { kk = e % BK; mm = e / BK; }
-      const int k = k0 + kk, m = m0 + mm;
-      float v = 0.f;
-      if ((A_EL % T == 0 || e < A_EL) && k < g.K && m < g.M) v = At[(long)m * g.a_sm + (long)k * g.a_sk];
-      ra[i] = v;
+      const int m = m0 + mm;
+      const int kc = kk <= klast ? kk : klast, mc = m < g.M ? m : g.M - 1;
+      st.a[i] = At[mc * (int)g.a_sm + kc * (int)g.a_sk];
     }
     int dh = 0, dw = 0;
     if (CONV) { dh = tap / 3 - 1; dw = tap % 3 - 1; }
@@ -77,50 +92,71 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_kernel(NNParams p) {
     for (int i = 0; i < NB; ++i) {
       const int c = tid + i * T;
       const int kk = c / (BN / VEC), nn = (c % (BN / VEC)) * VEC;
-      const int k = k0 + kk, n = n0 + nn;
-      const bool rowok = (B_CH % T == 0 || c < B_CH) && k < g.K;
+      const int n = n0 + nn;
+      const int kc = kk <= klast ? kk : klast;
       if (!CONV) {
         if (VEC == 4) {
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (rowok && n < g.N) v = *reinterpret_cast<const f32x4*>(X + (long)k * g.ldx + n);  // N%4==0 here
-          rb[i][0] = v[0]; rb[i][1] = v[1]; rb[i][2] = v[2]; rb[i][3] = v[3];
+          const int nc = n < g.N ? n : g.N - 4;  // N % 4 == 0 and N >= 4 on this path
+          const f32x4 v = *reinterpret_cast<const f32x4*>(Xt + (kc * (int)g.ldx + nc));
+          st.b[i][0] = v[0]; st.b[i][1] = v[1]; st.b[i][2] = v[2]; st.b[i][3] = v[3];
         } else {
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) rb[i][j] = (rowok && n + j < g.N) ? X[(long)k * g.ldx + n + j] : 0.f;
+          for (int j = 0; j < VEC; ++j) {
+            const int nj = n + j, nc = nj < g.N ? nj : g.N - 1;
+            st.b[i][j] = Xt[kc * (int)g.ldx + nc];
+          }
         }
       } else {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-          const int nj = n + j;
-          const int h = nj / p.W + dh, w = nj % p.W + dw;
-          const bool ok = rowok && nj < g.N && h >= 0 && h < p.H && w >= 0 && w < p.W;
-          rb[i][j] = ok ? X[(long)k * g.ldx + (long)h * p.W + w] : 0.f;
+          const int nj = n + j, nc = nj < g.N ? nj : g.N - 1;
+          const int h = nc / p.W + dh, w = nc % p.W + dw;
+          const int hc = h < 0 ? 0 : (h >= p.H ? p.H - 1 : h), wc = w < 0 ? 0 : (w >= p.W ? p.W - 1 : w);
+          st.b[i][j] = Xt[kc * (int)g.ldx + hc * p.W + wc];
         }
       }
     }
   };
 
-  auto stash = [&](int buf) {
+  auto stash = [&](int buf, int it, const Stage& st) {
     float* As = smem + buf * STAGE;
     float* Bs = As + BK * AS;
+    const int tap = CONV ? it / ktiles : 0;
+    const int k0 = (CONV ? it % ktiles : it) * BK;
+    const int klast = g.K - 1 - k0;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + i * T;
       int kk, mm;
       if (A_MFAST) { mm = e % BM; kk = e / BM; } else { kk = e % BK; mm = e / BK; }
-      if (A_EL % T == 0 || e < A_EL) As[kk * AS + mm] = ra[i];
+      const bool ok = kk <= klast && m0 + mm < g.M;
+      if (A_EL % T == 0 || e < A_EL) As[kk * AS + mm] = ok ? st.a[i] : 0.f;
     }
+    int dh = 0, dw = 0;
+    if (CONV) { dh = tap / 3 - 1; dw = tap % 3 - 1; }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int c = tid + i * T;
       const int kk = c / (BN / VEC), nn = (c % (BN / VEC)) * VEC;
+      const int n = n0 + nn;
+      const bool rowok = kk <= klast;
       if (B_CH % T == 0 || c < B_CH) {
-        if (VEC == 4) {
-          f32x4 v = {rb[i][0], rb[i][1], rb[i][2], rb[i][3]};
+        if (VEC == 4 && !CONV) {
+          const bool ok = rowok && n < g.N;
+          f32x4 v = {ok ? st.b[i][0] : 0.f, ok ? st.b[i][1] : 0.f, ok ? st.b[i][2] : 0.f, ok ? st.b[i][3] : 0.f};
           *reinterpret_cast<f32x4*>(Bs + kk * BS + nn) = v;
         } else {
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) Bs[kk * BS + nn + j] = rb[i][j];
+          for (int j = 0; j < VEC; ++j) {
+            const int nj = n + j;
+            bool ok = rowok && nj < g.N;
+            if (CONV) {
+              const int nc = nj < g.N ? nj : g.N - 1;
+              const int h = nc / p.W + dh, w = nc % p.W + dw;
+              ok = ok && h >= 0 && h < p.H && w >= 0 && w < p.W;
+            }
+            Bs[kk * BS + nn + j] = ok ? st.b[i][j] : 0.f;
+          }
         }
       }
     }
@@ -134,62 +170,116 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_kernel(NNParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load(0);
-  stash(0);
-  __syncthreads();
-  for (int it = 0; it < iters; ++it) {
-    const int buf = it & 1;
-    if (it + 1 < iters) load(it + 1);
+  // LDS operand reads are software-pipelined one MFMA k-step ahead (register double buffer),
+  // so a lone wave on a SIMD does not stall on ds_read latency between MFMA groups.
+  auto compute = [&](int buf) {
     const float* As = smem + buf * STAGE + (lane >> 5) * AS + wm * TM * 32 + (lane & 31);
     const float* Bs = smem + buf * STAGE + BK * AS + (lane >> 5) * BS + wn * TN * 32 + (lane & 31);
+    float a[2][TM], b[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[0][i] = As[i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[0][j] = Bs[j * 32];
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
-      float a[TM], b[TN];
+      const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+      if (kk + 2 < BK) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[kk * AS + i * 32];
+        for (int i = 0; i < TM; ++i) a[nxt][i] = As[(kk + 2) * AS + i * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bs[kk * BS + j * 32];
+        for (int j = 0; j < TN; ++j) b[nxt][j] = Bs[(kk + 2) * BS + j * 32];
+      }
+      if (PIN_SCHED) __builtin_amdgcn_sched_barrier(0);  // keep the next step's ds_reads AHEAD of this step's MFMAs
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+      if (PIN_SCHED) __builtin_amdgcn_sched_barrier(0);
     }
-    if (it + 1 < iters) stash(buf ^ 1);
+  };
+
+  // Global prefetch runs TWO stages ahead through two register sets (loop unrolled by two so the
+  // set index is static): 2 stages x (A+B) bytes per block stay in flight, which is what the
+  // small-K, HBM-bound 1x1 convs of the full-resolution levels need.
+  if (DEPTH == 2) {
+    Stage s0, s1;
+    load(0, s0);
+    if (iters > 1) load(1, s1);
+    stash(0, 0, s0);
     __syncthreads();
+    int it = 0;
+    for (; it + 1 < iters; it += 2) {
+      if (it + 2 < iters) load(it + 2, s0);
+      compute(0);
+      stash(1, it + 1, s1);
+      __syncthreads();
+      if (it + 3 < iters) load(it + 3, s1);
+      compute(1);
+      if (it + 2 < iters) stash(0, it + 2, s0);
+      __syncthreads();
+    }
+    if (it < iters) compute(0);  // odd tail: its stage was stashed into buffer 0 by the last iteration
+  } else {  // one stage ahead, one register set: fewer VGPRs -> more resident blocks
+    Stage s0;
+    load(0, s0);
+    stash(0, 0, s0);
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+      if (it + 1 < iters) load(it + 1, s0);
+      compute(it & 1);
+      if (it + 1 < iters) stash((it & 1) ^ 1, it + 1, s0);
+      __syncthreads();
+    }
   }
 
-  // epilogue: each store instruction writes two 128-byte row segments.  Residual loads of one
-  // 32x32 tile are issued back-to-back from clamped (always in-bounds) addresses so they overlap;
-  // a guarded load->add->store chain per element would serialise on HBM latency.
+  // epilogue.  Each store instruction writes two 128-byte row segments.  Offsets are 32-bit
+  // (per-image tensors are < 2^31 elements, checked on the host) = one VALU add per element on top
+  // of scalar row strides; a wave-uniform test selects an unguarded path for interior tiles.
+  // Residual loads of one 32x32 tile are issued back-to-back so their latencies overlap.
   const float* __restrict__ R = g.R ? g.R + o1 * g.r_s1 + o2 * g.r_s2 : nullptr;
   const float* __restrict__ RS = g.rowscale ? g.rowscale + o1 * g.rs_s1 + o2 * g.rs_s2 : nullptr;
+  const int ldy = (int)g.ldy, ldr = (int)g.ldr;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
-      const int mb = m0 + (wm * TM + i) * 32;
-      const int nc = n < g.N ? n : g.N - 1;
-      float res[16];
-      if (R) {
+      const int nb = n0 + (wn * TN + j) * 32, mb = m0 + (wm * TM + i) * 32;  // wave-uniform
+      const int n = nb + (lane & 31), mrow = mb + 4 * (lane >> 5);
+      const bool full = mb + 32 <= g.M && nb + 32 <= g.N;
+      if (full) {
+        const int offy = mrow * ldy + n;
+        float res[16];
+        if (R) {
+          const int offr = mrow * ldr + n;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mb + c_row(r, lane);
-          const int mc = m < g.M ? m : g.M - 1;
-          res[r] = R[(long)mc * g.ldr + nc];
+          for (int r = 0; r < 16; ++r) res[r] = R[offr + ((r & 3) + 8 * (r >> 2)) * ldr];
+          if (RS) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) res[r] *= RS[mrow + (r & 3) + 8 * (r >> 2)];
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Y[offy + ((r & 3) + 8 * (r >> 2)) * ldy] = acc[i][j][r] + res[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Y[offy + ((r & 3) + 8 * (r >> 2)) * ldy] = acc[i][j][r];
         }
-        if (RS) {
+      } else {
+        const int nc = n < g.N ? n : g.N - 1;
+        float res[16];
+        if (R) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int m = mb + c_row(r, lane);
-            res[r] *= RS[m < g.M ? m : g.M - 1];
+            const int m = mrow + (r & 3) + 8 * (r >> 2);
+            const int mc = m < g.M ? m : g.M - 1;
+            res[r] = R[mc * ldr + nc] * (RS ? RS[mc] : 1.f);
           }
         }
-      }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mb + c_row(r, lane);
-        if (m < g.M && n < g.N) Y[(long)m * g.ldy + n] = R ? acc[i][j][r] + res[r] : acc[i][j][r];
+        for (int r = 0; r < 16; ++r) {
+          const int m = mrow + (r & 3) + 8 * (r >> 2);
+          if (m < g.M && n < g.N) Y[m * ldy + n] = R ? acc[i][j][r] + res[r] : acc[i][j][r];
+        }
       }
     }
 }
@@ -202,10 +292,13 @@ int launch_nn_cfg(const NNParams& p, hipStream_t s) {
   dim3 grid((unsigned)tiles, (unsigned)(g.O1 * g.O2)), block(WM * WN * 64);
   const bool conv = p.taps == 9;
   const bool mfast = g.a_sm == 1;
+  static const int depth_env = getenv("PIR_NN_DEPTH") ? atoi(getenv("PIR_NN_DEPTH")) : 0;
+  const bool depth2 = depth_env ? depth_env == 2 : true;  // two-stage prefetch: 4% faster over the step's shapes
   const bool vec4 = !conv && g.N % 4 == 0 && g.ldx % 4 == 0 && g.x_s1 % 4 == 0 && g.x_s2 % 4 == 0 &&
                     (reinterpret_cast<uintptr_t>(g.X) & 15) == 0;
 #define PIR_NN_LAUNCH(MF, V, C) \
-  hipLaunchKernelGGL((gemm_nn_kernel<TM, TN, WM, WN, MF, V, C>), grid, block, 0, s, p)
+  do { if (depth2) hipLaunchKernelGGL((gemm_nn_kernel<TM, TN, WM, WN, MF, V, C, 2>), grid, block, 0, s, p); \
+       else hipLaunchKernelGGL((gemm_nn_kernel<TM, TN, WM, WN, MF, V, C, 1>), grid, block, 0, s, p); } while (0)
   if (conv) {
     if (mfast) PIR_NN_LAUNCH(true, 1, true); else PIR_NN_LAUNCH(false, 1, true);
   } else if (vec4) {
@@ -219,12 +312,17 @@ int launch_nn_cfg(const NNParams& p, hipStream_t s) {
 
 int launch_nn(const NNParams& p, hipStream_t s) {
   const int M = p.g.M;
+  const long batch = (long)p.g.O1 * p.g.O2;
   // pick the M-tile height (multiple of 32) that wastes the fewest padded rows
   if (M <= 32) return launch_nn_cfg<1, 2, 1, 4>(p, s);   // 32 x 256
   if (M <= 64) return launch_nn_cfg<2, 2, 1, 4>(p, s);   // 64 x 256
   const long pad96 = pir_cdiv(M, 96) * 96, pad128 = pir_cdiv(M, 128) * 128;
-  if (pad96 < pad128) return launch_nn_cfg<3, 2, 1, 4>(p, s);  // 96 x 256
-  return launch_nn_cfg<2, 2, 2, 2>(p, s);                       // 128 x 128
+  const bool use96 = pad96 < pad128;
+  const long blocks = use96 ? pir_cdiv(M, 96) * pir_cdiv(p.g.N, 256) * batch : pir_cdiv(M, 128) * pir_cdiv(p.g.N, 128) * batch;
+  // low-resolution levels: too few 128-row tiles to give every CU two blocks -> 64 x 128 tiles
+  if (blocks < 2L * PIR_NUM_CU && pir_cdiv(M, 64) * 64 <= pad128) return launch_nn_cfg<1, 2, 2, 2>(p, s);
+  if (use96) return launch_nn_cfg<3, 2, 1, 4>(p, s);  // 96 x 256
+  return launch_nn_cfg<2, 2, 2, 2>(p, s);              // 128 x 128
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -486,6 +584,10 @@ extern "C" int pir_gemm_nn(const pir_gemm_nn_t* a, pir_stream_t stream) {
   PIR_CHECK_ARG(a->M > 0 && a->K > 0 && a->N > 0 && a->O1 > 0 && a->O2 > 0);
   PIR_CHECK_ARG((long)a->O1 * a->O2 <= 65535);
   PIR_CHECK_ARG(a->rowscale == nullptr || a->R != nullptr);
+  // kernels index one batch item with 32-bit offsets
+  PIR_CHECK_ARG((long)a->M * a->ldy < 2147483647L && (long)a->K * a->ldx < 2147483647L);
+  PIR_CHECK_ARG(a->R == nullptr || (long)a->M * a->ldr < 2147483647L);
+  PIR_CHECK_ARG((long)(a->M - 1) * a->a_sm + (long)(a->K - 1) * a->a_sk < 2147483647L);
   NNParams p;
   p.g = *a;
   p.taps = 1; p.flip = 0; p.H = 0; p.W = 0; p.a_st = 0;
@@ -497,6 +599,7 @@ extern "C" int pir_conv3x3(const float* A, long a_st, long a_sm, long a_sk, int 
                            const float* R, long r_bs,
                            int B, int M, int K, int H, int W, pir_stream_t stream) {
   PIR_CHECK_ARG(A && X && Y && B > 0 && M > 0 && K > 0 && H > 0 && W > 0 && B <= 65535);
+  PIR_CHECK_ARG((long)(M > K ? M : K) * H * W < 2147483647L);
   NNParams p;
   pir_gemm_nn_t& g = p.g;
   g.A = A; g.a_s1 = 0; g.a_s2 = 0; g.a_sm = a_sm; g.a_sk = a_sk;
