@@ -132,6 +132,19 @@ size_t pir_dwconv3x3_wgrad_ws_floats(int B, int C, int H, int W);
 int pir_dwconv3x3_wgrad(const float* dy, long dy_bs, const float* x, long x_bs, float* dw,
                         float* ws, size_t ws_floats, int B, int C, int H, int W, pir_stream_t stream);
 
+/* Fused backward of one depthwise conv: dx = dwconv^T(dy) and dw in a single pass over dy and x. */
+size_t pir_dwconv3x3_bwd_ws_floats(int B, int C, int H, int W);
+int pir_dwconv3x3_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* w,
+                      float* dx, long dx_bs, float* dw, float* ws, size_t ws_floats,
+                      int B, int C, int H, int W, pir_stream_t stream);
+/* Fused backward of the GDFN tail (net/model.py:96-97): from x = project_in output ([B][2hid]) and dg
+ * ([B][hid]) to dx ([B][2hid]) and the depthwise weight gradient dw ([2hid][9]) in ONE pass:
+ * the pre-gate tensor t = dwconv(x) and dt are recomputed on a halo-extended tile in LDS. */
+size_t pir_gdfn_dwconv_bwd_ws_floats(int B, int hid, int H, int W);
+int pir_gdfn_dwconv_bwd(const float* x, long x_bs, const float* w, const float* dg, long dg_bs,
+                        float* dx, long dx_bs, float* dw, float* ws, size_t ws_floats,
+                        int B, int hid, int H, int W, pir_stream_t stream);
+
 /* ------------------------------------------------------------------ MDTA small-matrix stages
  * Row sums of squares over the pixel axis: out[b][c] = sum_n x[b][c][n]^2 (the squared
  * L2 norms F.normalize needs, net/model.py:127-128). */

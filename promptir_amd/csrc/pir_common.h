@@ -34,6 +34,20 @@ __device__ __forceinline__ int pir_xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
+// Division of a small index by a runtime divisor without the ~30-instruction integer-divide sequence:
+// magic = floor(2^32 / d) + 1 (host side, pir_magic), exact for n * d < 2^32.
+// d == 1 has no 32-bit magic: encoded as 0 and handled by the select.
+static inline unsigned pir_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)(0x100000000ULL / d) + 1u; }
+__device__ __forceinline__ int pir_fastdiv(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }
+
+// gelu_erf(v) and its derivative from ONE erf evaluation (F.gelu default, net/model.py:97)
+__device__ __forceinline__ void pir_gelu_both(float v, float& g, float& dg) {
+  const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * v * v);
+  g = v * cdf;
+  dg = cdf + v * pdf;
+}
+
 __device__ __forceinline__ float pir_wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -56,4 +70,22 @@ __device__ __forceinline__ float pir_block_sum(float v, float* red) {
   float t = 0.f;
   for (int i = 0; i < nw; ++i) t += red[i];
   return t;
+}
+
+// Reduce NV per-thread values over the workgroup with ONE barrier: wave64 shuffle reduction of each
+// value, one LDS row per wave, then threads 0..NV-1 add the rows in fixed order (deterministic).
+// `red` holds >= 4*NV floats.  Returns the total in threads 0..NV-1 (value index = threadIdx.x).
+template <int NV>
+__device__ __forceinline__ float pir_block_sum_many(const float (&v)[NV], float* red) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int t = 0; t < NV; ++t) {
+    const float s = pir_wave_sum(v[t]);
+    if (lane == 0) red[wid * NV + t] = s;
+  }
+  __syncthreads();
+  float tot = 0.f;
+  if (threadIdx.x < NV)
+    for (int w = 0; w < nw; ++w) tot += red[w * NV + threadIdx.x];
+  return tot;
 }

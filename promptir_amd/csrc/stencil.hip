@@ -10,11 +10,12 @@
 //         GATE_FWD  g = gelu(dw(x)[:hid]) * dw(x)[hid:] (FeedForward.dwconv + gate, :96-97)
 //         GATE_BWD  dt from dg, recomputing t = dw(x)
 //         WGRAD     dw[c][tap] partial sums           (weight gradient of either dwconv)
+//         BWD       dx = dw3x3^T(dy) AND the dw partial sums in one pass over dy and x
 #include "pir_common.h"
 
 namespace {
 
-enum { MODE_FWD = 0, MODE_GATE_FWD = 1, MODE_GATE_BWD = 2, MODE_WGRAD = 3 };
+enum { MODE_FWD = 0, MODE_GATE_FWD = 1, MODE_GATE_BWD = 2, MODE_WGRAD = 3, MODE_BWD = 4 };
 
 struct DwArgs {
   const float* x; long x_bs;
@@ -26,6 +27,7 @@ struct DwArgs {
   int hid;                   // gate modes: channel offset of the second half
   int flip;
   int CT, LPR, strips, SR, tiles_r, tiles_c;
+  unsigned magic_spr, magic_lpr;  // fast division by LPR+2 and LPR
 };
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
@@ -37,11 +39,11 @@ __device__ __forceinline__ float gelu_erf_grad(float v) {
 
 template <int VEC>
 __device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__ plane, int H, int W, int h0, int w0,
-                                           int rows, int LPR, int LS) {
+                                           int rows, int LPR, int LS, unsigned magic_spr) {
   const int slots_per_row = LPR + 2;
   const int total = rows * slots_per_row;
   for (int s = threadIdx.x; s < total; s += blockDim.x) {
-    const int lr = s / slots_per_row, j = s % slots_per_row;
+    const int lr = pir_fastdiv(s, magic_spr), j = s - lr * slots_per_row;
     const int h = h0 - 1 + lr, col = w0 + (j - 1) * VEC;
     float* dst = lds + lr * LS + j * VEC;
     if (VEC == 4) {
@@ -83,19 +85,21 @@ template <int VEC, int MODE>
 __global__ void dwconv_kernel(DwArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr bool GATE = (MODE == MODE_GATE_FWD || MODE == MODE_GATE_BWD);
+  constexpr bool TWO = GATE || MODE == MODE_BWD;   // two staged tiles
+  constexpr bool SUMS = MODE == MODE_WGRAD || MODE == MODE_BWD;
   const int LS = (a.LPR + 2) * VEC;
   const int RT = a.strips * a.SR;
+  // FWD / gate modes: one workgroup per (plane, row tile, column tile).  Modes that produce weight-gradient
+  // sums walk all row tiles of their (plane, column tile) so the sums are reduced once per workgroup.
   int bid = blockIdx.x;
   const int tile_c = bid % a.tiles_c; bid /= a.tiles_c;
-  const int tile_r = bid % a.tiles_r; bid /= a.tiles_r;
+  int tr_begin = 0, tr_end = a.tiles_r;
+  if (!SUMS) { tr_begin = bid % a.tiles_r; tr_end = tr_begin + 1; bid /= a.tiles_r; }
   const int b = bid / a.C, c = bid % a.C;
-  const int h0 = tile_r * RT, w0 = tile_c * a.CT;
+  const int w0 = tile_c * a.CT;
   const long HW = (long)a.H * a.W;
-
   const float* __restrict__ xp = a.x + b * a.x_bs + c * HW;
-  stage_tile<VEC>(lds, xp, a.H, a.W, h0, w0, RT + 2, a.LPR, LS);
   float* lds2 = lds + (RT + 2) * LS;
-  if (GATE) stage_tile<VEC>(lds2, xp + a.hid * HW, a.H, a.W, h0, w0, RT + 2, a.LPR, LS);
 
   float k1[9], k2[9];
 #pragma unroll
@@ -103,23 +107,34 @@ __global__ void dwconv_kernel(DwArgs a) {
     k1[t] = a.w[c * 9 + (a.flip ? 8 - t : t)];
     if (GATE) k2[t] = a.w[(c + a.hid) * 9 + t];
   }
-  __syncthreads();
-
-  const int s = threadIdx.x / a.LPR, q = threadIdx.x % a.LPR;
+  const int s = pir_fastdiv(threadIdx.x, a.magic_lpr), q = threadIdx.x - s * a.LPR;
   const int col = w0 + q * VEC;
   const bool active = s < a.strips && col < a.W;
   float wsum[9];
-  if (MODE == MODE_WGRAD) {
+  if (SUMS) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) wsum[t] = 0.f;
   }
+
+  for (int tile_r = tr_begin; tile_r < tr_end; ++tile_r) {
+  const int h0 = tile_r * RT;
+  if (tile_r != tr_begin) __syncthreads();
+  if (MODE == MODE_BWD) {  // tile 1 = dy (stencil input), tile 2 = x (weight-gradient operand)
+    stage_tile<VEC>(lds, a.dz + b * a.dz_bs + c * HW, a.H, a.W, h0, w0, RT + 2, a.LPR, LS, a.magic_spr);
+    stage_tile<VEC>(lds2, xp, a.H, a.W, h0, w0, RT + 2, a.LPR, LS, a.magic_spr);
+  } else {
+    stage_tile<VEC>(lds, xp, a.H, a.W, h0, w0, RT + 2, a.LPR, LS, a.magic_spr);
+    if (GATE) stage_tile<VEC>(lds2, xp + a.hid * HW, a.H, a.W, h0, w0, RT + 2, a.LPR, LS, a.magic_spr);
+  }
+  __syncthreads();
+
   if (active) {
     float r0[VEC + 2], r1[VEC + 2], r2[VEC + 2];
     float u0[VEC + 2], u1[VEC + 2], u2[VEC + 2];
     const int lr0 = s * a.SR;
     read_row<VEC>(lds + lr0 * LS, q, r0);
     read_row<VEC>(lds + (lr0 + 1) * LS, q, r1);
-    if (GATE) {
+    if (TWO) {
       read_row<VEC>(lds2 + lr0 * LS, q, u0);
       read_row<VEC>(lds2 + (lr0 + 1) * LS, q, u1);
     }
@@ -127,9 +142,22 @@ __global__ void dwconv_kernel(DwArgs a) {
       const int h = h0 + lr0 + i;
       if (h >= a.H) break;
       read_row<VEC>(lds + (lr0 + i + 2) * LS, q, r2);
-      if (GATE) read_row<VEC>(lds2 + (lr0 + i + 2) * LS, q, u2);
+      if (TWO) read_row<VEC>(lds2 + (lr0 + i + 2) * LS, q, u2);
       const long off = (long)h * a.W + col;
-      if (MODE == MODE_FWD) {
+      if (MODE == MODE_BWD) {
+        float o[VEC];
+        stencil_row<VEC>(r0, r1, r2, k1, o);   // k1 holds the flipped taps (a.flip = 1)
+        float* yp = a.y + b * a.y_bs + c * HW + off;
+        if (VEC == 4) { f32x4 v = {o[0], o[1], o[2], o[3]}; *reinterpret_cast<f32x4*>(yp) = v; } else yp[0] = o[0];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            wsum[d] += r1[j + 1] * u0[j + d];
+            wsum[3 + d] += r1[j + 1] * u1[j + d];
+            wsum[6 + d] += r1[j + 1] * u2[j + d];
+          }
+      } else if (MODE == MODE_FWD) {
         float o[VEC];
         stencil_row<VEC>(r0, r1, r2, k1, o);
         float* yp = a.y + b * a.y_bs + c * HW + off;
@@ -151,8 +179,10 @@ __global__ void dwconv_kernel(DwArgs a) {
         else dg[0] = gp[0];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-          d1[j] = dg[j] * t2[j] * gelu_erf_grad(t1[j]);
-          d2[j] = dg[j] * gelu_erf(t1[j]);
+          float ge, gd;
+          pir_gelu_both(t1[j], ge, gd);
+          d1[j] = dg[j] * t2[j] * gd;
+          d2[j] = dg[j] * ge;
         }
         float* p1 = a.y + b * a.y_bs + c * HW + off;
         float* p2 = p1 + a.hid * HW;
@@ -176,17 +206,15 @@ __global__ void dwconv_kernel(DwArgs a) {
           }
       }
 #pragma unroll
-      for (int j = 0; j < VEC + 2; ++j) { r0[j] = r1[j]; r1[j] = r2[j]; if (GATE) { u0[j] = u1[j]; u1[j] = u2[j]; } }
+      for (int j = 0; j < VEC + 2; ++j) { r0[j] = r1[j]; r1[j] = r2[j]; if (TWO) { u0[j] = u1[j]; u1[j] = u2[j]; } }
     }
   }
-  if (MODE == MODE_WGRAD) {
-    __shared__ float red[16];
-    const int part = (b * a.tiles_r + tile_r) * a.tiles_c + tile_c;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const float tot = pir_block_sum(wsum[t], red);
-      if (threadIdx.x == 0) a.ws[((long)part * a.C + c) * 9 + t] = tot;
-    }
+  }  // row tiles
+  if (SUMS) {
+    __shared__ float red[4 * 9];
+    const float tot = pir_block_sum_many<9>(wsum, red);
+    const int part = b * a.tiles_c + tile_c;
+    if (threadIdx.x < 9) a.ws[((long)part * a.C + c) * 9 + threadIdx.x] = tot;
   }
 }
 
@@ -213,10 +241,12 @@ DwPlan dw_plan(int H, int W, bool aligned, int ntiles_lds) {
 
 template <int MODE>
 int launch_dw(DwArgs a, bool aligned, hipStream_t s) {
-  constexpr bool GATE = (MODE == MODE_GATE_FWD || MODE == MODE_GATE_BWD);
+  constexpr bool GATE = (MODE == MODE_GATE_FWD || MODE == MODE_GATE_BWD || MODE == MODE_BWD);
   DwPlan p = dw_plan(a.H, a.W, aligned, GATE ? 2 : 1);
+  a.magic_spr = pir_magic(p.LPR + 2); a.magic_lpr = pir_magic(p.LPR);
   a.CT = p.CT; a.LPR = p.LPR; a.strips = p.strips; a.SR = p.SR; a.tiles_r = p.tiles_r; a.tiles_c = p.tiles_c;
-  const long blocks = (long)a.B * a.C * p.tiles_r * p.tiles_c;
+  constexpr bool SUMS = MODE == MODE_WGRAD || MODE == MODE_BWD;
+  const long blocks = (long)a.B * a.C * (SUMS ? 1 : p.tiles_r) * p.tiles_c;
   if (blocks <= 0 || blocks > 2147483647L) return PIR_EINVAL;
   if (p.lds_bytes > 64 * 1024) return PIR_EINVAL;
   if (p.vec == 4)
@@ -291,7 +321,7 @@ extern "C" size_t pir_dwconv3x3_wgrad_ws_floats(int B, int C, int H, int W) {
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
   // worst case over the two vector widths
   DwPlan p4 = dw_plan(H, W, W % 4 == 0, 1), p1 = dw_plan(H, W, false, 1);
-  const size_t t4 = (size_t)p4.tiles_r * p4.tiles_c, t1 = (size_t)p1.tiles_r * p1.tiles_c;
+  const size_t t4 = (size_t)p4.tiles_c, t1 = (size_t)p1.tiles_c;
   return (size_t)B * (t4 > t1 ? t4 : t1) * C * 9;
 }
 
@@ -306,9 +336,33 @@ extern "C" int pir_dwconv3x3_wgrad(const float* dy, long dy_bs, const float* x, 
   a.B = B; a.C = C; a.H = H; a.W = W;
   const bool aligned = al16(x) && al16(dy) && x_bs % 4 == 0 && dy_bs % 4 == 0;
   DwPlan p = dw_plan(H, W, aligned && W % 4 == 0, 1);
-  const long parts = (long)B * p.tiles_r * p.tiles_c;
+  const long parts = (long)B * p.tiles_c;
   if ((size_t)parts * C * 9 > ws_floats) return PIR_ENOMEM;
   int st = launch_dw<MODE_WGRAD>(a, aligned, (hipStream_t)stream);
+  if (st) return st;
+  return pir_reduce_partials(ws, (long)C * 9, (int)parts, 1.f, 0, dw, (long)C * 9, stream);
+}
+
+// dx = dw3x3^T(dy) and dw in ONE pass over dy and x (2 reads + 1 write instead of 3 + 1)
+extern "C" size_t pir_dwconv3x3_bwd_ws_floats(int B, int C, int H, int W) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+  DwPlan p4 = dw_plan(H, W, W % 4 == 0, 2), p1 = dw_plan(H, W, false, 2);
+  const size_t t4 = (size_t)p4.tiles_c, t1 = (size_t)p1.tiles_c;
+  return (size_t)B * (t4 > t1 ? t4 : t1) * C * 9;
+}
+
+extern "C" int pir_dwconv3x3_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* w,
+                                 float* dx, long dx_bs, float* dw, float* ws, size_t ws_floats,
+                                 int B, int C, int H, int W, pir_stream_t stream) {
+  PIR_CHECK_ARG(dy && x && w && dx && dw && ws && B > 0 && C > 0 && H > 0 && W > 0);
+  DwArgs a = {};
+  a.x = x; a.x_bs = x_bs; a.w = w; a.flip = 1; a.y = dx; a.y_bs = dx_bs; a.dz = dy; a.dz_bs = dy_bs; a.ws = ws;
+  a.B = B; a.C = C; a.H = H; a.W = W;
+  const bool aligned = al16(x) && al16(dy) && al16(dx) && x_bs % 4 == 0 && dy_bs % 4 == 0 && dx_bs % 4 == 0;
+  DwPlan p = dw_plan(H, W, aligned && W % 4 == 0, 2);
+  const long parts = (long)B * p.tiles_c;
+  if ((size_t)parts * C * 9 > ws_floats) return PIR_ENOMEM;
+  int st = launch_dw<MODE_BWD>(a, aligned, (hipStream_t)stream);
   if (st) return st;
   return pir_reduce_partials(ws, (long)C * 9, (int)parts, 1.f, 0, dw, (long)C * 9, stream);
 }

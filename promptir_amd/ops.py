@@ -306,6 +306,32 @@ def dwconv_gate_backward(x, w, dg):
     return dt
 
 
+def dwconv_backward(dy, x, w, dw_out=None):
+    """dx = dwconv^T(dy) and dw in one pass (pir_dwconv3x3_bwd)."""
+    dy, x = _planes(dy), _planes(x)
+    b, c, h, wd = x.shape
+    dx = torch.empty((b, c, h, wd), dtype=torch.float32, device=x.device)
+    dw = _grad_out(w, dw_out)
+    ws = workspace(lib.pir_dwconv3x3_bwd_ws_floats(b, c, h, wd), x.device)
+    check(lib.pir_dwconv3x3_bwd(dy.data_ptr(), _bs(dy), x.data_ptr(), _bs(x), w.data_ptr(), dx.data_ptr(), _bs(dx),
+                                dw.data_ptr(), ws.data_ptr(), ws.numel(), b, c, h, wd, _stream()), "pir_dwconv3x3_bwd")
+    return dx, dw
+
+
+def gdfn_dwconv_backward(x, w, dg, dw_out=None):
+    """Backward of g = gelu(dw(x)[:hid]) * dw(x)[hid:] in one pass: returns (dx, dw)."""
+    x, dg = _planes(x), _planes(dg)
+    b, c2, h, wd = x.shape
+    hid = c2 // 2
+    dx = torch.empty((b, c2, h, wd), dtype=torch.float32, device=x.device)
+    dw = _grad_out(w, dw_out)
+    ws = workspace(lib.pir_gdfn_dwconv_bwd_ws_floats(b, hid, h, wd), x.device)
+    check(lib.pir_gdfn_dwconv_bwd(x.data_ptr(), _bs(x), w.data_ptr(), dg.data_ptr(), _bs(dg), dx.data_ptr(), _bs(dx),
+                                  dw.data_ptr(), ws.data_ptr(), ws.numel(), b, hid, h, wd, _stream()),
+          "pir_gdfn_dwconv_bwd")
+    return dx, dw
+
+
 def reduce_partials(parts, stride, count_parts, out, count, alpha=1.0, accumulate=False):
     check(lib.pir_reduce_partials(parts.data_ptr(), stride, count_parts, alpha, int(accumulate), out.data_ptr(), count,
                                   _stream()), "pir_reduce_partials")
@@ -479,6 +505,9 @@ class DwConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            dx, dw = dwconv_backward(dy, x, w, ctx.sink)     # one fused pass over dy and x
+            return dx, _ret(dw, ctx.sink)
         dx = dwconv_forward(dy, w, flip=True) if ctx.needs_input_grad[0] else None
         dw = dwconv_wgrad(dy, x, w, ctx.sink) if ctx.needs_input_grad[1] else None
         return dx, _ret(dw, ctx.sink)
@@ -497,9 +526,7 @@ class DwConvGateFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dg):
         x, w = ctx.saved_tensors
-        dt = dwconv_gate_backward(x, w, dg)
-        dx = dwconv_forward(dt, w, flip=True) if ctx.needs_input_grad[0] else None
-        dw = dwconv_wgrad(dt, x, w, ctx.sink) if ctx.needs_input_grad[1] else None
+        dx, dw = gdfn_dwconv_backward(x, w, dg, ctx.sink)    # gate-backward + dw^T + weight gradient fused
         return dx, _ret(dw, ctx.sink)
 
 

@@ -92,6 +92,29 @@ def test_dwconv_gate(b, hid, h, w):
     close(ops.dwconv_gate_backward(x.to(DEV), wt.to(DEV), dg.to(DEV)), t.grad)
 
 
+@pytest.mark.parametrize("b,hid,h,w", [(2, 5, 16, 16), (1, 127, 9, 11), (1, 3, 128, 128), (2, 2, 40, 256), (1, 4, 8, 8),
+                                       (1, 2, 70, 300), (3, 3, 1, 4)])
+def test_fused_stencil_backwards(b, hid, h, w):
+    """pir_gdfn_dwconv_bwd and pir_dwconv3x3_bwd vs autograd of the unfused PyTorch ops (incl. multi-tile and
+    the W % 4 != 0 fallback)."""
+    from promptir_amd import ops
+
+    x, wt, dg = rnd("x", b, 2 * hid, h, w), rnd("w", 2 * hid, 1, 3, 3), rnd("dg", b, hid, h, w)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    t = F.conv2d(xr, wr, padding=1, groups=2 * hid)
+    (F.gelu(t[:, :hid]) * t[:, hid:]).backward(dg)
+    dx, dw = ops.gdfn_dwconv_backward(x.to(DEV), wt.to(DEV), dg.to(DEV))
+    close(dx, xr.grad, rtol=5e-5)
+    close(dw, wr.grad, rtol=1e-4)
+
+    dy = rnd("dy", b, 2 * hid, h, w)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    F.conv2d(xr, wr, padding=1, groups=2 * hid).backward(dy)
+    dx, dw = ops.dwconv_backward(dy.to(DEV), x.to(DEV), wt.to(DEV))
+    close(dx, xr.grad)
+    close(dw, wr.grad, rtol=5e-5)
+
+
 @pytest.mark.parametrize("b,c,h,w,bias", [(2, 48, 8, 8, True), (1, 704, 4, 6, True), (2, 320, 3, 5, False),
                                           (1, 96, 16, 16, False), (2, 7, 9, 11, True)])
 def test_layernorm(b, c, h, w, bias):

@@ -98,6 +98,10 @@ def bench_dw(B):
         dg = r(B, hid, S, S)
         t = timeit(lambda: ops.dwconv_gate_backward(x2, w2, dg))
         print(f"{name:18s} gate bwd hid={hid:4d}: {t*1e6:8.1f} us {4.0*x2.numel()*2.5/t/1e9:7.0f} GB/s")
+        t = timeit(lambda: ops.gdfn_dwconv_backward(x2, w2, dg))
+        print(f"{name:18s} gdfn fused bwd hid={hid:4d}: {t*1e6:8.1f} us {4.0*x2.numel()*2.5/t/1e9:7.0f} GB/s (x+dg read, dx written)")
+        t = timeit(lambda: ops.dwconv_backward(y, x, w))
+        print(f"{name:18s} dw fused bwd C={3*C:4d}: {t*1e6:8.1f} us {12.0*x.numel()/t/1e9:7.0f} GB/s (dy+x read, dx written)")
 
 
 def bench_ln(B):
