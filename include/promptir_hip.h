@@ -37,6 +37,10 @@ int pir_abi_version(void);
 /* name of the code-object architecture the kernels were built for ("gfx950") */
 const char* pir_arch(void);
 
+/* tuning / A-B knob used by tools/ktune.py: knob 0 = gemm_nn tile config, 1 = gemm_nt tile config,
+ * 2 = gemm_nt split count; value -1 (knobs 0,1) or 0 (knob 2) restores the built-in heuristic. */
+int pir_tune_set(int knob, int value);
+
 /* ------------------------------------------------------------------ GEMM core
  * Batched  Y[o][m][n] = sum_k A[o](m,k) * X[o][k][n]  (+ rowscale[o][m] * R[o][m][n])
  *   o = o1*O2 + o2 (two-level batch so that (batch, head) slices of a qkv buffer

@@ -50,6 +50,7 @@ P, L, I, Z, F, S = c_float_p, c_long, c_int, c_size_t, c_float, stream_t
 SIGNATURES = {
     "pir_abi_version": (I, []),
     "pir_arch": (C.c_char_p, []),
+    "pir_tune_set": (I, [I, I]),
     "pir_gemm_nn": (I, [C.POINTER(GemmNN), S]),
     "pir_conv3x3": (I, [P, L, L, L, I, P, L, P, L, P, L, I, I, I, I, I, S]),
     "pir_gemm_nt_ws_floats": (Z, [I, I, I, I, I]),

@@ -22,6 +22,9 @@ constexpr int BK = 16;  // k-depth of one LDS stage (8 MFMA k-steps)
 #endif
 constexpr bool PIN_SCHED = PIR_PIN_SCHED;
 
+// tuning overrides (pir_tune_set): -1 / 0 = automatic
+int g_nn_cfg = -1, g_nt_cfg = -1, g_nt_splits = 0;
+
 __device__ __forceinline__ int c_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 // ---------------------------------------------------------------------------------------------
@@ -314,9 +317,18 @@ int launch_nn(const NNParams& p, hipStream_t s) {
   const int M = p.g.M;
   const long batch = (long)p.g.O1 * p.g.O2;
   // pick the M-tile height (multiple of 32) that wastes the fewest padded rows
-  if (M <= 32) return launch_nn_cfg<1, 2, 1, 4>(p, s);   // 32 x 256
-  if (M <= 64) return launch_nn_cfg<2, 2, 1, 4>(p, s);   // 64 x 256
+  if (g_nn_cfg < 0 && M <= 32) return launch_nn_cfg<1, 2, 1, 4>(p, s);   // 32 x 256
+  if (g_nn_cfg < 0 && M <= 64) return launch_nn_cfg<2, 2, 1, 4>(p, s);   // 64 x 256
   const long pad96 = pir_cdiv(M, 96) * 96, pad128 = pir_cdiv(M, 128) * 128;
+  if (g_nn_cfg >= 0) {
+    switch (g_nn_cfg) {
+      case 0: return launch_nn_cfg<1, 2, 1, 4>(p, s);
+      case 1: return launch_nn_cfg<2, 2, 1, 4>(p, s);
+      case 2: return launch_nn_cfg<3, 2, 1, 4>(p, s);
+      case 3: return launch_nn_cfg<2, 2, 2, 2>(p, s);
+      default: return launch_nn_cfg<1, 2, 2, 2>(p, s);
+    }
+  }
   const bool use96 = pad96 < pad128;
   const long blocks = use96 ? pir_cdiv(M, 96) * pir_cdiv(p.g.N, 256) * batch : pir_cdiv(M, 128) * pir_cdiv(p.g.N, 128) * batch;
   // low-resolution levels: too few 128-row tiles to give every CU two blocks -> 64 x 128 tiles
@@ -553,7 +565,11 @@ struct NTPlan {
 
 NTPlan nt_plan(int M1, int M2, int N, int O, int BR) {
   NTPlan pl;
-  if (M1 <= 64 && M2 <= 64) { pl.cfg = 0; pl.bm = 64; pl.bn = 64; }
+  if (g_nt_cfg >= 0) {
+    pl.cfg = g_nt_cfg;
+    pl.bm = g_nt_cfg == 0 ? 64 : 128;
+    pl.bn = g_nt_cfg == 0 || g_nt_cfg == 1 ? 64 : (g_nt_cfg == 2 ? 96 : 128);
+  } else if (M1 <= 64 && M2 <= 64) { pl.cfg = 0; pl.bm = 64; pl.bn = 64; }
   else if (M2 <= 64) { pl.cfg = 1; pl.bm = 128; pl.bn = 64; }
   else {
     const long pad96 = pir_cdiv(M2, 96) * 96, pad128 = pir_cdiv(M2, 128) * 128;
@@ -565,6 +581,7 @@ NTPlan nt_plan(int M1, int M2, int N, int O, int BR) {
   long want = pir_cdiv(3L * PIR_NUM_CU, tiles);          // ~3 blocks per CU overall
   long max_by_work = total / 16 > 0 ? total / 16 : 1;     // at least 16 stages (512 pixels) per split
   long s = want < max_by_work ? want : max_by_work;
+  if (g_nt_splits > 0) s = g_nt_splits < total ? g_nt_splits : total;
   if (s < 1) s = 1;
   if (s > 1024) s = 1024;
   pl.splits = (int)s;
@@ -578,6 +595,15 @@ void launch_nt_cfg(const NTParams& p, dim3 grid, bool vec4, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int pir_tune_set(int knob, int value) {
+  switch (knob) {
+    case 0: g_nn_cfg = value; return PIR_OK;
+    case 1: g_nt_cfg = value; return PIR_OK;
+    case 2: g_nt_splits = value; return PIR_OK;
+    default: return PIR_EINVAL;
+  }
+}
 
 extern "C" int pir_gemm_nn(const pir_gemm_nn_t* a, pir_stream_t stream) {
   PIR_CHECK_ARG(a && a->A && a->X && a->Y);
@@ -616,7 +642,8 @@ extern "C" size_t pir_gemm_nt_ws_floats(int M1, int M2, int N, int O, int BR) {
   if (M1 <= 0 || M2 <= 0 || N <= 0 || O <= 0 || BR <= 0) return 0;
   // the launcher may swap the operands so that the larger extent plays M1: size for the worst of both
   NTPlan a = nt_plan(M1, M2, N, O, BR), b = nt_plan(M2, M1, N, O, BR);
-  const int s = a.splits > b.splits ? a.splits : b.splits;
+  int s = a.splits > b.splits ? a.splits : b.splits;
+  if (g_nt_splits > s) s = g_nt_splits;
   return (size_t)s * O * M1 * M2;
 }
 
