@@ -108,11 +108,12 @@ int pir_gemm_nt(const pir_gemm_nt_t* args, pir_stream_t stream);
 int pir_layernorm_fwd(const float* x, long x_bs, const float* weight, const float* bias,
                       float* y, long y_bs, float* mean, float* rstd,
                       int B, int C, int HW, pir_stream_t stream);
-/* dx; dweight/dbias partial sums are written to ws ([nblk][2][C]) and reduced into dweight/dbias. */
+/* dx (+ dres, the gradient arriving over the residual connection net/model.py:193-194, if not NULL);
+ * dweight/dbias partial sums are written to ws ([nblk][2][C]) and reduced into dweight/dbias. */
 size_t pir_layernorm_bwd_ws_floats(int B, int C, int HW);
 int pir_layernorm_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* weight,
                       int with_bias, const float* mean, const float* rstd,
-                      float* dx, long dx_bs, float* dweight, float* dbias,
+                      float* dx, long dx_bs, const float* dres, long dres_bs, float* dweight, float* dbias,
                       float* ws, size_t ws_floats, int B, int C, int HW, pir_stream_t stream);
 
 /* ------------------------------------------------------------------ depthwise 3x3 stencil

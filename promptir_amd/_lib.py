@@ -57,7 +57,7 @@ SIGNATURES = {
     "pir_gemm_nt": (I, [C.POINTER(GemmNT), S]),
     "pir_layernorm_fwd": (I, [P, L, P, P, P, L, P, P, I, I, I, S]),
     "pir_layernorm_bwd_ws_floats": (Z, [I, I, I]),
-    "pir_layernorm_bwd": (I, [P, L, P, L, P, I, P, P, P, L, P, P, P, Z, I, I, I, S]),
+    "pir_layernorm_bwd": (I, [P, L, P, L, P, I, P, P, P, L, P, L, P, P, P, Z, I, I, I, S]),
     "pir_dwconv3x3": (I, [P, L, P, I, P, L, I, I, I, I, S]),
     "pir_dwconv3x3_gate": (I, [P, L, P, P, L, I, I, I, I, S]),
     "pir_dwconv3x3_gate_bwd": (I, [P, L, P, P, L, P, L, I, I, I, I, S]),

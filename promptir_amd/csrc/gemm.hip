@@ -16,7 +16,10 @@
 
 namespace {
 
-constexpr int BK = 16;  // k-depth of one LDS stage (8 MFMA k-steps)
+#ifndef PIR_BK
+#define PIR_BK 16
+#endif
+constexpr int BK = PIR_BK;  // k-depth of one LDS stage (PIR_BK/2 MFMA k-steps)
 #ifndef PIR_PIN_SCHED
 #define PIR_PIN_SCHED 0  /* A/B on MI355X: pinning the ds_read/MFMA order is 1.5% slower overall */
 #endif

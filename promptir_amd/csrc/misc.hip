@@ -64,12 +64,33 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, c
     out[i] = a[i] + b[i];
 }
 
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ parts, long stride, int S,
-                                                              float alpha, int accumulate, float* __restrict__ out,
-                                                              long count) {
-  for (long j = blockIdx.x * (long)blockDim.x + threadIdx.x; j < count; j += (long)gridDim.x * blockDim.x) {
+// out[j] = alpha * sum_s parts[s*stride + j]: 64 outputs x GR split-groups per workgroup; each thread sums
+// its group's rows with four independent accumulators (loads in flight), groups are combined through LDS
+// in a fixed order (deterministic).
+template <int GR>
+__global__ __launch_bounds__(64 * GR) void reduce_partials_kernel(const float* __restrict__ parts, long stride, int S,
+                                                                  float alpha, int accumulate, float* __restrict__ out,
+                                                                  long count) {
+  __shared__ float red[GR][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long j = blockIdx.x * 64L + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (j < count) {
+    int k = grp;
+    for (; k + 3 * GR < S; k += 4 * GR) {
+      s0 += parts[(long)k * stride + j];
+      s1 += parts[(long)(k + GR) * stride + j];
+      s2 += parts[(long)(k + 2 * GR) * stride + j];
+      s3 += parts[(long)(k + 3 * GR) * stride + j];
+    }
+    for (; k < S; k += GR) s0 += parts[(long)k * stride + j];
+  }
+  red[grp][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0 && j < count) {
     float s = 0.f;
-    for (int k = 0; k < S; ++k) s += parts[k * stride + j];
+#pragma unroll
+    for (int q = 0; q < GR; ++q) s += red[q][lane];
     s *= alpha;
     out[j] = accumulate ? out[j] + s : s;
   }
@@ -141,8 +162,13 @@ extern "C" int pir_add(const float* a, const float* b, float* out, long count, p
 extern "C" int pir_reduce_partials(const float* parts, long stride, int S, float alpha, int accumulate,
                                    float* out, long count, pir_stream_t stream) {
   PIR_CHECK_ARG(parts && out && S > 0 && count > 0);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream,
-                     parts, stride, S, alpha, accumulate, out, count);
+  const unsigned blocks = (unsigned)pir_cdiv(count, 64);
+  if (S >= 64)
+    hipLaunchKernelGGL((reduce_partials_kernel<16>), dim3(blocks), dim3(1024), 0, (hipStream_t)stream,
+                       parts, stride, S, alpha, accumulate, out, count);
+  else
+    hipLaunchKernelGGL((reduce_partials_kernel<4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       parts, stride, S, alpha, accumulate, out, count);
   return pir_launch_status();
 }
 

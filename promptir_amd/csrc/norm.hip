@@ -14,12 +14,12 @@ constexpr int LN_WAVES = 4;
 constexpr float LN_EPS = 1e-5f;
 
 // NREG: compile-time bound on channels per wave kept in registers (0 = re-read from memory/L2)
-template <int NREG>
-__global__ __launch_bounds__(LN_PIX* LN_WAVES) void ln_fwd_kernel(
+template <int NREG, int WAVES>
+__global__ __launch_bounds__(LN_PIX* WAVES) void ln_fwd_kernel(
     const float* __restrict__ x, long x_bs, const float* __restrict__ weight, const float* __restrict__ bias,
     float* __restrict__ y, long y_bs, float* __restrict__ mean_out, float* __restrict__ rstd_out,
     int C, int HW, int tiles) {
-  __shared__ float red[LN_WAVES][LN_PIX];
+  __shared__ float red[WAVES][LN_PIX];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int b = blockIdx.x / tiles, p = (blockIdx.x % tiles) * LN_PIX + lane;
   const bool ok = p < HW;
@@ -30,35 +30,41 @@ __global__ __launch_bounds__(LN_PIX* LN_WAVES) void ln_fwd_kernel(
   if (NREG > 0) {
 #pragma unroll
     for (int i = 0; i < NREG; ++i) {
-      const int c = wid + i * LN_WAVES;
+      const int c = wid + i * WAVES;
       v[i] = (ok && c < C) ? xb[(long)c * HW] : 0.f;
       s += v[i];
     }
   } else {
-    for (int c = wid; c < C; c += LN_WAVES) s += ok ? xb[(long)c * HW] : 0.f;
+    for (int c = wid; c < C; c += WAVES) s += ok ? xb[(long)c * HW] : 0.f;
   }
   red[wid][lane] = s;
   __syncthreads();
-  const float mu = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+  float tsum = 0.f;
+#pragma unroll
+  for (int w = 0; w < WAVES; ++w) tsum += red[w][lane];
+  const float mu = tsum / (float)C;
   __syncthreads();
 
   float ss = 0.f;
   if (NREG > 0) {
 #pragma unroll
     for (int i = 0; i < NREG; ++i) {
-      const int c = wid + i * LN_WAVES;
+      const int c = wid + i * WAVES;
       const float d = (c < C) ? v[i] - mu : 0.f;
       ss += d * d;
     }
   } else {
-    for (int c = wid; c < C; c += LN_WAVES) {
+    for (int c = wid; c < C; c += WAVES) {
       const float d = ok ? xb[(long)c * HW] - mu : 0.f;
       ss += d * d;
     }
   }
   red[wid][lane] = ss;
   __syncthreads();
-  const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+  float vsum = 0.f;
+#pragma unroll
+  for (int w = 0; w < WAVES; ++w) vsum += red[w][lane];
+  const float var = vsum / (float)C;
   const float rstd = 1.f / sqrtf(var + LN_EPS);
   if (wid == 0 && ok) {
     mean_out[(long)b * HW + p] = mu;
@@ -70,11 +76,11 @@ __global__ __launch_bounds__(LN_PIX* LN_WAVES) void ln_fwd_kernel(
   if (NREG > 0) {
 #pragma unroll
     for (int i = 0; i < NREG; ++i) {
-      const int c = wid + i * LN_WAVES;
+      const int c = wid + i * WAVES;
       if (c < C) yb[(long)c * HW] = (v[i] - shift) * rstd * weight[c] + (bias ? bias[c] : 0.f);
     }
   } else {
-    for (int c = wid; c < C; c += LN_WAVES)
+    for (int c = wid; c < C; c += WAVES)
       yb[(long)c * HW] = (xb[(long)c * HW] - shift) * rstd * weight[c] + (bias ? bias[c] : 0.f);
   }
 }
@@ -85,7 +91,7 @@ __global__ __launch_bounds__(LN_PIX* LN_WAVES) void ln_fwd_kernel(
 __global__ __launch_bounds__(LN_PIX* LN_WAVES) void ln_bwd_dx_kernel(
     const float* __restrict__ dy, long dy_bs, const float* __restrict__ x, long x_bs,
     const float* __restrict__ weight, int with_bias, const float* __restrict__ mean, const float* __restrict__ rstd,
-    float* __restrict__ dx, long dx_bs, int C, int HW, int tiles) {
+    float* __restrict__ dx, long dx_bs, const float* __restrict__ dres, long dres_bs, int C, int HW, int tiles) {
   __shared__ float red[2][LN_WAVES][LN_PIX];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int b = blockIdx.x / tiles, p = (blockIdx.x % tiles) * LN_PIX + lane;
@@ -116,7 +122,94 @@ __global__ __launch_bounds__(LN_PIX* LN_WAVES) void ln_bwd_dx_kernel(
     float r;
     if (with_bias) r = rs * (g - m1 - (xv - mu) * rs * m2);
     else r = rs * g - rs * rs * rs * (xv - mu) * m2;
+    if (dres) r += dres[b * dres_bs + (long)c * HW + p];
     db[(long)c * HW] = r;
+  }
+}
+
+// One pass for C <= 4*NREG: a persistent workgroup walks (image, 64-pixel tile) pairs with its
+// channel slice of dy and x in registers, writes dx (+ optional residual gradient) and keeps the
+// per-channel dweight / dbias sums of its pixels in registers; one shuffle reduction per channel at
+// the end gives this workgroup's partial row ws[block][2][C].  dy and x are read exactly once.
+template <int NREG, int WAVES>
+__global__ __launch_bounds__(LN_PIX* WAVES) void ln_bwd_fused_kernel(
+    const float* __restrict__ dy, long dy_bs, const float* __restrict__ x, long x_bs,
+    const float* __restrict__ weight, int with_bias, const float* __restrict__ mean, const float* __restrict__ rstd,
+    float* __restrict__ dx, long dx_bs, const float* __restrict__ dres, long dres_bs,
+    float* __restrict__ ws, int B, int C, int HW, int tiles) {
+  __shared__ float red[2][WAVES][LN_PIX];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: channel
+  float accw[NREG], accb[NREG];                                      // tests and weight loads go scalar
+#pragma unroll
+  for (int i = 0; i < NREG; ++i) { accw[i] = 0.f; accb[i] = 0.f; }
+  const long total = (long)B * tiles;
+  for (long t = blockIdx.x; t < total; t += gridDim.x) {
+    const int b = (int)(t / tiles), p = (int)(t % tiles) * LN_PIX + lane;
+    const bool ok = p < HW;
+    const int pc = ok ? p : HW - 1;                 // clamped: loads are unconditional, stores masked
+    const int off0 = wid * HW + pc;                 // 32-bit offset inside one image (C*HW < 2^31)
+    // wave-uniform per-image bases: the per-channel step is added on the scalar side
+    const float* __restrict__ dyb = dy + b * dy_bs;
+    const float* __restrict__ xb = x + b * x_bs;
+    const float* __restrict__ rb = dres ? dres + b * dres_bs : nullptr;
+    float* __restrict__ ob = dx + b * dx_bs;
+    const float mu = mean[(long)b * HW + pc];
+    const float rs = rstd[(long)b * HW + pc];
+    // phase A: issue every load of this tile (channel index clamped -> no branches, all in flight)
+    float g[NREG], xh[NREG], rr[NREG];
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+      const int c = wid + i * WAVES;             // wave-uniform
+      const int ic = c < C ? i : 0;                 // clamp to a valid channel of this wave
+      const long step = (long)ic * WAVES * HW;
+      g[i] = (dyb + step)[off0];
+      xh[i] = (xb + step)[off0];
+      rr[i] = rb ? (rb + step)[off0] : 0.f;
+    }
+    // phase B: arithmetic
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+      const int c = wid + i * WAVES;
+      const bool live = c < C;
+      const float d = live ? g[i] : 0.f;
+      const float xv = xh[i];
+      const float xn = with_bias ? (xv - mu) * rs : xv * rs;   // what multiplies the weight in forward
+      if (ok) { accw[i] += d * xn; accb[i] += d; }
+      g[i] = d * weight[live ? c : 0];
+      const float second = with_bias ? xn : xv;                // BiasFree: second sum is over g*x
+      s1 += g[i];
+      s2 += g[i] * second;
+      xh[i] = with_bias ? xn : xv - mu;                        // factor of m2 in dx
+    }
+    __syncthreads();
+    red[0][wid][lane] = s1;
+    red[1][wid][lane] = s2;
+    __syncthreads();
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) { m1 += red[0][w][lane]; m2 += red[1][w][lane]; }
+    m1 /= (float)C; m2 /= (float)C;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+      const int c = wid + i * WAVES;
+      if (c < C) {
+        const long step = (long)i * WAVES * HW;
+        float r;
+        if (with_bias) r = rs * (g[i] - m1 - xh[i] * m2);
+        else r = rs * g[i] - rs * rs * rs * xh[i] * m2;
+        r += rr[i];
+        if (ok) (ob + step)[off0] = r;
+      }
+    }
+  }
+  float* row = ws + (long)blockIdx.x * 2 * C;
+#pragma unroll
+  for (int i = 0; i < NREG; ++i) {
+    const int c = wid + i * WAVES;
+    const float sw = pir_wave_sum(accw[i]), sb = pir_wave_sum(accb[i]);
+    if (lane == 0 && c < C) { row[c] = sw; row[C + c] = sb; }
   }
 }
 
@@ -179,13 +272,16 @@ extern "C" int pir_layernorm_fwd(const float* x, long x_bs, const float* weight,
                                  int B, int C, int HW, pir_stream_t stream) {
   PIR_CHECK_ARG(x && weight && y && mean && rstd && B > 0 && C > 0 && HW > 0);
   const int tiles = (int)pir_cdiv(HW, LN_PIX);
-  dim3 grid((unsigned)((long)B * tiles)), block(LN_PIX * LN_WAVES);
+  dim3 grid((unsigned)((long)B * tiles));
   hipStream_t s = (hipStream_t)stream;
-#define PIR_LN(NR) hipLaunchKernelGGL((ln_fwd_kernel<NR>), grid, block, 0, s, x, x_bs, weight, bias, y, y_bs, mean, rstd, C, HW, tiles)
-  if (C <= 64) PIR_LN(16);
-  else if (C <= 128) PIR_LN(32);
-  else if (C <= 256) PIR_LN(64);
-  else PIR_LN(0);
+#define PIR_LN(NR, WV) hipLaunchKernelGGL((ln_fwd_kernel<NR, WV>), grid, dim3(LN_PIX * WV), 0, s, x, x_bs, weight, bias, y, y_bs, mean, rstd, C, HW, tiles)
+  const bool few = (long)B * tiles < 4L * PIR_NUM_CU;   // low-resolution levels: 16 waves per pixel tile
+  if (few && C > 64 && C <= 1024) {
+    if (C <= 256) PIR_LN(16, 16); else if (C <= 512) PIR_LN(32, 16); else PIR_LN(64, 16);
+  } else if (C <= 64) PIR_LN(16, 4);
+  else if (C <= 128) PIR_LN(32, 4);
+  else if (C <= 256) PIR_LN(64, 4);
+  else PIR_LN(0, 4);
 #undef PIR_LN
   return pir_launch_status();
 }
@@ -199,31 +295,56 @@ static int ln_param_splits(int B, int C, int HW) {
   return (int)s;
 }
 
+static int ln_fused_blocks(int B, int HW) {
+  const long total = (long)B * pir_cdiv(HW, LN_PIX);
+  long g = pir_cdiv(total, 4);                      // >= 4 pixel tiles per workgroup amortise its tail
+  if (g > 8L * PIR_NUM_CU) g = 8L * PIR_NUM_CU;
+  if (total < 2L * PIR_NUM_CU) g = total;           // tiny tensors: one tile per workgroup
+  return (int)(g < 1 ? 1 : g);
+}
+static bool ln_use16(int B, int C, int HW) { return (long)B * pir_cdiv(HW, LN_PIX) < 4L * PIR_NUM_CU && C > 64 && C <= 512; }
+
 extern "C" size_t pir_layernorm_bwd_ws_floats(int B, int C, int HW) {
   if (B <= 0 || C <= 0 || HW <= 0) return 0;
-  return (size_t)ln_param_splits(B, C, HW) * 2 * C;
+  const size_t a = (size_t)ln_param_splits(B, C, HW) * 2 * C, b = (size_t)ln_fused_blocks(B, HW) * 2 * C;
+  return a > b ? a : b;
 }
 
 extern "C" int pir_layernorm_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* weight,
                                  int with_bias, const float* mean, const float* rstd,
-                                 float* dx, long dx_bs, float* dweight, float* dbias,
+                                 float* dx, long dx_bs, const float* dres, long dres_bs,
+                                 float* dweight, float* dbias,
                                  float* ws, size_t ws_floats, int B, int C, int HW, pir_stream_t stream) {
   PIR_CHECK_ARG(dy && x && weight && mean && rstd && dx && dweight && ws && B > 0 && C > 0 && HW > 0);
   PIR_CHECK_ARG(!with_bias || dbias);
-  const int S = ln_param_splits(B, C, HW);
-  if ((size_t)S * 2 * C > ws_floats) return PIR_ENOMEM;
   hipStream_t s = (hipStream_t)stream;
   const int tiles = (int)pir_cdiv(HW, LN_PIX);
-  hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3((unsigned)((long)B * tiles)), dim3(LN_PIX * LN_WAVES), 0, s,
-                     dy, dy_bs, x, x_bs, weight, with_bias, mean, rstd, dx, dx_bs, C, HW, tiles);
-  int st = pir_launch_status();
-  if (st) return st;
-  hipLaunchKernelGGL(ln_bwd_param_kernel, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s,
-                     dy, dy_bs, x, x_bs, with_bias, mean, rstd, ws, B, C, HW);
-  st = pir_launch_status();
-  if (st) return st;
+  int S;
+  const bool w16 = ln_use16(B, C, HW);
+  if (C <= 128 || w16) {
+    S = ln_fused_blocks(B, HW);
+    if ((size_t)S * 2 * C > ws_floats) return PIR_ENOMEM;
+#define PIR_LNB(NR, WV) hipLaunchKernelGGL((ln_bwd_fused_kernel<NR, WV>), dim3((unsigned)S), dim3(LN_PIX * WV), 0, s, \
+      dy, dy_bs, x, x_bs, weight, with_bias, mean, rstd, dx, dx_bs, dres, dres_bs, ws, B, C, HW, tiles)
+    if (w16) { if (C <= 192) PIR_LNB(12, 16); else if (C <= 384) PIR_LNB(24, 16); else PIR_LNB(32, 16); }
+    else if (C <= 48) PIR_LNB(12, 4); else if (C <= 64) PIR_LNB(16, 4); else if (C <= 96) PIR_LNB(24, 4); else PIR_LNB(32, 4);
+#undef PIR_LNB
+    int st = pir_launch_status();
+    if (st) return st;
+  } else {
+    S = ln_param_splits(B, C, HW);
+    if ((size_t)S * 2 * C > ws_floats) return PIR_ENOMEM;
+    hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3((unsigned)((long)B * tiles)), dim3(LN_PIX * LN_WAVES), 0, s,
+                       dy, dy_bs, x, x_bs, weight, with_bias, mean, rstd, dx, dx_bs, dres, dres_bs, C, HW, tiles);
+    int st = pir_launch_status();
+    if (st) return st;
+    hipLaunchKernelGGL(ln_bwd_param_kernel, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s,
+                       dy, dy_bs, x, x_bs, with_bias, mean, rstd, ws, B, C, HW);
+    st = pir_launch_status();
+    if (st) return st;
+  }
   // partials are [S][2][C]: reduce the two halves separately
-  st = pir_reduce_partials(ws, 2L * C, S, 1.f, 0, dweight, C, stream);
+  int st = pir_reduce_partials(ws, 2L * C, S, 1.f, 0, dweight, C, stream);
   if (st) return st;
   if (with_bias) st = pir_reduce_partials(ws + C, 2L * C, S, 1.f, 0, dbias, C, stream);
   return st;

@@ -186,9 +186,15 @@ class TransformerBlock(nn.Module):
         self.ffn = FeedForward(dim, ffn_expansion_factor, bias)
 
     def forward(self, x):
-        x = self.attn(self.norm1(x), residual=x)   # residual add fused into project_out's epilogue
-        x = self.ffn(self.norm2(x), residual=x)
-        return x
+        _check_channels(x, self.norm1.body.normalized_shape[0], "TransformerBlock")
+        a, f = self.attn, self.ffn
+        # one autograd node per block; residual adds live in the project_out epilogues (forward) and in
+        # the LayerNorm-backward kernel (backward).  Equivalent to
+        #   x = self.attn(self.norm1(x), residual=x); x = self.ffn(self.norm2(x), residual=x)
+        return ops.TransformerBlockFn.apply(
+            x, self.norm1.body.weight, getattr(self.norm1.body, "bias", None), a.temperature, a.qkv.weight,
+            a.qkv_dwconv.weight, a.project_out.weight, self.norm2.body.weight, getattr(self.norm2.body, "bias", None),
+            f.project_in.weight, f.dwconv.weight, f.project_out.weight, a.num_heads)
 
 
 ##########################################################################

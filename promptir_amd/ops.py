@@ -251,8 +251,11 @@ def layernorm_forward(x, weight, bias):
     return y, mean, rstd
 
 
-def layernorm_backward(dy, x, weight, with_bias, mean, rstd, dweight=None, dbias=None):
+def layernorm_backward(dy, x, weight, with_bias, mean, rstd, dweight=None, dbias=None, dres=None):
+    """dx (+ dres: gradient arriving over the residual connection), dweight, dbias."""
     dy, x = _planes(dy), _planes(x)
+    if dres is not None:
+        dres = _planes(dres)
     b, c, h, w = x.shape
     dx = torch.empty((b, c, h, w), dtype=torch.float32, device=x.device)
     dweight = _grad_out(weight, dweight)
@@ -260,7 +263,8 @@ def layernorm_backward(dy, x, weight, with_bias, mean, rstd, dweight=None, dbias
     nws = lib.pir_layernorm_bwd_ws_floats(b, c, h * w)
     ws = workspace(nws, x.device)
     check(lib.pir_layernorm_bwd(dy.data_ptr(), _bs(dy), x.data_ptr(), _bs(x), weight.data_ptr(), int(with_bias),
-                                mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _bs(dx), dweight.data_ptr(),
+                                mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _bs(dx), _p(dres),
+                                _bs(dres) if dres is not None else 0, dweight.data_ptr(),
                                 _p(dbias), ws.data_ptr(), ws.numel(), b, c, h * w, _stream()), "pir_layernorm_bwd")
     return dx, dweight, dbias
 
@@ -545,6 +549,65 @@ class MdtaCoreFn(torch.autograd.Function):
         qkv, temperature, attn, gram, sumsq = ctx.saved_tensors
         dqkv, dtemp = mdta_core_backward(dout, qkv, temperature, ctx.heads, attn, gram, sumsq, ctx.sink)
         return dqkv, _ret(dtemp, ctx.sink), None
+
+
+class TransformerBlockFn(torch.autograd.Function):
+    """x -> x + attn(norm1(x)) -> (+ ffn(norm2(.))) (net/model.py:192-196) as ONE autograd node.
+
+    Same kernels as the fine-grained Functions above; what the fusion buys is that the two residual
+    gradient joins happen inside the LayerNorm-backward kernel (`dres`) instead of as eager adds issued by
+    the autograd engine, and 2 instead of ~12 autograd nodes per block on the host.
+    """
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, temperature, wqkv, wdw1, wproj, n2w, n2b, win, wdw2, wout, heads):
+        _require_gpu(x, n1w, n1b, temperature, wqkv, wdw1, wproj, n2w, n2b, win, wdw2, wout)
+        xn1, m1, r1 = layernorm_forward(x, n1w, n1b)
+        qkv0 = conv1x1_forward(xn1, wqkv)
+        qkv = dwconv_forward(qkv0, wdw1)
+        out, attn, gram, sumsq = mdta_core_forward(qkv, temperature, heads)
+        x1 = conv1x1_forward(out, wproj, residual=x)
+        xn2, m2, r2 = layernorm_forward(x1, n2w, n2b)
+        h0 = conv1x1_forward(xn2, win)
+        g = dwconv_gate_forward(h0, wdw2)
+        x2 = conv1x1_forward(g, wout, residual=x1)
+        ctx.heads = heads
+        ctx.with_bias = (n1b is not None, n2b is not None)
+        ctx.sinks = tuple(_sink(p) for p in (n1w, n1b, temperature, wqkv, wdw1, wproj, n2w, n2b, win, wdw2, wout))
+        ctx.save_for_backward(x, n1w, temperature, wqkv, wdw1, wproj, n2w, win, wdw2, wout,
+                              xn1, m1, r1, qkv0, qkv, attn, gram, sumsq, out, x1, xn2, m2, r2, h0, g)
+        return x2
+
+    @staticmethod
+    def backward(ctx, dx2):
+        (x, n1w, temperature, wqkv, wdw1, wproj, n2w, win, wdw2, wout,
+         xn1, m1, r1, qkv0, qkv, attn, gram, sumsq, out, x1, xn2, m2, r2, h0, g) = ctx.saved_tensors
+        s_n1w, s_n1b, s_t, s_qkv, s_dw1, s_proj, s_n2w, s_n2b, s_in, s_dw2, s_out = ctx.sinks
+        # ---- GDFN branch
+        dg = conv1x1_dgrad(dx2, wout)
+        d_wout = conv1x1_wgrad(dx2, g, wout, s_out)
+        dh0, d_wdw2 = gdfn_dwconv_backward(h0, wdw2, dg, s_dw2)
+        del dg
+        dxn2 = conv1x1_dgrad(dh0, win)
+        d_win = conv1x1_wgrad(dh0, xn2, win, s_in)
+        del dh0
+        dx1, d_n2w, d_n2b = layernorm_backward(dxn2, x1, n2w, ctx.with_bias[1], m2, r2, s_n2w, s_n2b, dres=dx2)
+        del dxn2
+        # ---- MDTA branch
+        dout = conv1x1_dgrad(dx1, wproj)
+        d_wproj = conv1x1_wgrad(dx1, out, wproj, s_proj)
+        dqkv, d_temp = mdta_core_backward(dout, qkv, temperature, ctx.heads, attn, gram, sumsq, s_t)
+        del dout
+        dqkv0, d_wdw1 = dwconv_backward(dqkv, qkv0, wdw1, s_dw1)
+        del dqkv
+        dxn1 = conv1x1_dgrad(dqkv0, wqkv)
+        d_wqkv = conv1x1_wgrad(dqkv0, xn1, wqkv, s_qkv)
+        del dqkv0
+        dx, d_n1w, d_n1b = layernorm_backward(dxn1, x, n1w, ctx.with_bias[0], m1, r1, s_n1w, s_n1b, dres=dx1)
+        return (dx, _ret(d_n1w, s_n1w), _ret(d_n1b, s_n1b) if ctx.with_bias[0] else None, _ret(d_temp, s_t),
+                _ret(d_wqkv, s_qkv), _ret(d_wdw1, s_dw1), _ret(d_wproj, s_proj),
+                _ret(d_n2w, s_n2w), _ret(d_n2b, s_n2b) if ctx.with_bias[1] else None,
+                _ret(d_win, s_in), _ret(d_wdw2, s_dw2), _ret(d_wout, s_out), None)
 
 
 class PixelUnshuffleFn(torch.autograd.Function):
