@@ -59,8 +59,16 @@ typedef struct {
   const float* rowscale; long rs_s1, rs_s2;
   int M, K, N;
   int O1, O2;
+  /* optional: A pre-split into three bf16 pieces by pir_split_bf16x3 (layout [3][M][a3_kp], unbatched).
+   * When set, the bf16x3 matrix-core path reads it instead of splitting A on the fly. NULL otherwise. */
+  const void* A3; int a3_kp;
 } pir_gemm_nn_t;
 int pir_gemm_nn(const pir_gemm_nn_t* args, pir_stream_t stream);
+/* out[part][m][k] (bf16, k padded with zeros to kp = multiple of 16) = part-th piece of the exact split
+ * W(m,k) = hi + mid + lo with W(m,k) = W[m*sm + k*sk]; out holds 3*M*kp bf16. Used once per weight
+ * tensor and step for the forward (sm=K, sk=1) and input-gradient (sm=1, sk=Cin) orientations. */
+size_t pir_split_bf16x3_bytes(int M, int K);
+int pir_split_bf16x3(const float* W, int M, int K, long sm, long sk, void* out, pir_stream_t stream);
 
 /* Dense 3x3 convolution, stride 1, zero pad 1, no bias, as 9 shifted GEMMs:
  *   Y[b][m][h][w] = sum_{k,dh,dw} Wt[(dh+1)*3+(dw+1)](m,k) * X[b][k][h+dh][w+dw]

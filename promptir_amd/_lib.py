@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PIR_LIB", os.path.join(_HERE, "libpromptir_hip.so"))  # PIR_LIB: A/B builds in tools/
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_float_p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 c_long = C.c_long
@@ -29,6 +29,7 @@ class GemmNN(C.Structure):
         ("R", c_float_p), ("r_s1", c_long), ("r_s2", c_long), ("ldr", c_long),
         ("rowscale", c_float_p), ("rs_s1", c_long), ("rs_s2", c_long),
         ("M", c_int), ("K", c_int), ("N", c_int), ("O1", c_int), ("O2", c_int),
+        ("A3", c_float_p), ("a3_kp", c_int),
     ]
 
 
@@ -52,6 +53,8 @@ SIGNATURES = {
     "pir_arch": (C.c_char_p, []),
     "pir_tune_set": (I, [I, I]),
     "pir_gemm_nn": (I, [C.POINTER(GemmNN), S]),
+    "pir_split_bf16x3_bytes": (Z, [I, I]),
+    "pir_split_bf16x3": (I, [P, I, I, L, L, P, S]),
     "pir_conv3x3": (I, [P, L, L, L, I, P, L, P, L, P, L, I, I, I, I, I, S]),
     "pir_gemm_nt_ws_floats": (Z, [I, I, I, I, I]),
     "pir_gemm_nt": (I, [C.POINTER(GemmNT), S]),

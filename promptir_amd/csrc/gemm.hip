@@ -11,7 +11,7 @@
 // xf32/TF32 on gfx950, and the 1e-4 parity bar rules out bf16 inputs).
 // Operand lane maps (cdna_hip_programming.md §3): A: lane l holds A[i=l&31][k=l>>5],
 // B: B[k=l>>5][j=l&31]; C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
-#include "pir_common.h"
+#include "gemm_common.h"
 #include <stdlib.h>
 
 namespace {
@@ -26,9 +26,9 @@ constexpr int BK = PIR_BK;  // k-depth of one LDS stage (PIR_BK/2 MFMA k-steps)
 constexpr bool PIN_SCHED = PIR_PIN_SCHED;
 
 // tuning overrides (pir_tune_set): -1 / 0 = automatic
-int g_nn_cfg = -1, g_nt_cfg = -1, g_nt_splits = 0;
+int g_nn_cfg = -1, g_nt_cfg = -1, g_nt_splits = 0, g_nn_x3 = -1;
 
-__device__ __forceinline__ int c_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+__device__ __forceinline__ int c_row(int reg, int lane) { return pir_c_row(reg, lane); }
 
 // ---------------------------------------------------------------------------------------------
 // gemm_nn
@@ -239,55 +239,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_kernel(NNParams p) {
     }
   }
 
-  // epilogue.  Each store instruction writes two 128-byte row segments.  Offsets are 32-bit
-  // (per-image tensors are < 2^31 elements, checked on the host) = one VALU add per element on top
-  // of scalar row strides; a wave-uniform test selects an unguarded path for interior tiles.
-  // Residual loads of one 32x32 tile are issued back-to-back so their latencies overlap.
-  const float* __restrict__ R = g.R ? g.R + o1 * g.r_s1 + o2 * g.r_s2 : nullptr;
-  const float* __restrict__ RS = g.rowscale ? g.rowscale + o1 * g.rs_s1 + o2 * g.rs_s2 : nullptr;
-  const int ldy = (int)g.ldy, ldr = (int)g.ldr;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int nb = n0 + (wn * TN + j) * 32, mb = m0 + (wm * TM + i) * 32;  // wave-uniform
-      const int n = nb + (lane & 31), mrow = mb + 4 * (lane >> 5);
-      const bool full = mb + 32 <= g.M && nb + 32 <= g.N;
-      if (full) {
-        const int offy = mrow * ldy + n;
-        float res[16];
-        if (R) {
-          const int offr = mrow * ldr + n;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) res[r] = R[offr + ((r & 3) + 8 * (r >> 2)) * ldr];
-          if (RS) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) res[r] *= RS[mrow + (r & 3) + 8 * (r >> 2)];
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) Y[offy + ((r & 3) + 8 * (r >> 2)) * ldy] = acc[i][j][r] + res[r];
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) Y[offy + ((r & 3) + 8 * (r >> 2)) * ldy] = acc[i][j][r];
-        }
-      } else {
-        const int nc = n < g.N ? n : g.N - 1;
-        float res[16];
-        if (R) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = mrow + (r & 3) + 8 * (r >> 2);
-            const int mc = m < g.M ? m : g.M - 1;
-            res[r] = R[mc * ldr + nc] * (RS ? RS[mc] : 1.f);
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mrow + (r & 3) + 8 * (r >> 2);
-          if (m < g.M && n < g.N) Y[m * ldy + n] = R ? acc[i][j][r] + res[r] : acc[i][j][r];
-        }
-      }
-    }
+  pir_nn_epilogue<TM, TN>(acc, g, Y, o1, o2, m0, n0, wm, wn, lane);
 }
 
 template <int TM, int TN, int WM, int WN>
@@ -604,6 +556,7 @@ extern "C" int pir_tune_set(int knob, int value) {
     case 0: g_nn_cfg = value; return PIR_OK;
     case 1: g_nt_cfg = value; return PIR_OK;
     case 2: g_nt_splits = value; return PIR_OK;
+    case 3: g_nn_x3 = value; return PIR_OK;
     default: return PIR_EINVAL;
   }
 }
@@ -617,6 +570,7 @@ extern "C" int pir_gemm_nn(const pir_gemm_nn_t* a, pir_stream_t stream) {
   PIR_CHECK_ARG((long)a->M * a->ldy < 2147483647L && (long)a->K * a->ldx < 2147483647L);
   PIR_CHECK_ARG(a->R == nullptr || (long)a->M * a->ldr < 2147483647L);
   PIR_CHECK_ARG((long)(a->M - 1) * a->a_sm + (long)(a->K - 1) * a->a_sk < 2147483647L);
+  if (pir_nn_x3_wanted(a, g_nn_x3)) return pir_nn_x3_launch(a, g_nn_cfg, (hipStream_t)stream);
   NNParams p;
   p.g = *a;
   p.taps = 1; p.flip = 0; p.H = 0; p.W = 0; p.a_st = 0;
@@ -636,7 +590,7 @@ extern "C" int pir_conv3x3(const float* A, long a_st, long a_sm, long a_sk, int 
   g.Y = Y; g.y_s1 = y_bs; g.y_s2 = 0; g.ldy = (long)H * W;
   g.R = R; g.r_s1 = r_bs; g.r_s2 = 0; g.ldr = (long)H * W;
   g.rowscale = nullptr; g.rs_s1 = 0; g.rs_s2 = 0;
-  g.M = M; g.K = K; g.N = H * W; g.O1 = B; g.O2 = 1;
+  g.M = M; g.K = K; g.N = H * W; g.O1 = B; g.O2 = 1; g.A3 = nullptr; g.a3_kp = 0;
   p.taps = 9; p.flip = flip; p.H = H; p.W = W; p.a_st = a_st;
   return launch_nn(p, (hipStream_t)stream);
 }

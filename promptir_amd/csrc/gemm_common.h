@@ -1,0 +1,64 @@
+// Shared pieces of the gemm_nn kernels (fp32 MFMA and bf16x3 split MFMA): C/D fragment map and epilogue.
+#pragma once
+#include "pir_common.h"
+
+// row of accumulator register `reg` of a 32x32 MFMA result (col = lane & 31); same for every dtype on gfx950
+__device__ __forceinline__ int pir_c_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+template <int TM, int TN>
+__device__ __forceinline__ void pir_nn_epilogue(const f32x16 (&acc)[TM][TN], const pir_gemm_nn_t& g, float* __restrict__ Y,
+                                                int o1, int o2, int m0, int n0, int wm, int wn, int lane) {
+  // epilogue.  Each store instruction writes two 128-byte row segments.  Offsets are 32-bit
+  // (per-image tensors are < 2^31 elements, checked on the host) = one VALU add per element on top
+  // of scalar row strides; a wave-uniform test selects an unguarded path for interior tiles.
+  // Residual loads of one 32x32 tile are issued back-to-back so their latencies overlap.
+  const float* __restrict__ R = g.R ? g.R + o1 * g.r_s1 + o2 * g.r_s2 : nullptr;
+  const float* __restrict__ RS = g.rowscale ? g.rowscale + o1 * g.rs_s1 + o2 * g.rs_s2 : nullptr;
+  const int ldy = (int)g.ldy, ldr = (int)g.ldr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nb = n0 + (wn * TN + j) * 32, mb = m0 + (wm * TM + i) * 32;  // wave-uniform
+      const int n = nb + (lane & 31), mrow = mb + 4 * (lane >> 5);
+      const bool full = mb + 32 <= g.M && nb + 32 <= g.N;
+      if (full) {
+        const int offy = mrow * ldy + n;
+        float res[16];
+        if (R) {
+          const int offr = mrow * ldr + n;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) res[r] = R[offr + ((r & 3) + 8 * (r >> 2)) * ldr];
+          if (RS) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) res[r] *= RS[mrow + (r & 3) + 8 * (r >> 2)];
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Y[offy + ((r & 3) + 8 * (r >> 2)) * ldy] = acc[i][j][r] + res[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Y[offy + ((r & 3) + 8 * (r >> 2)) * ldy] = acc[i][j][r];
+        }
+      } else {
+        const int nc = n < g.N ? n : g.N - 1;
+        float res[16];
+        if (R) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = mrow + (r & 3) + 8 * (r >> 2);
+            const int mc = m < g.M ? m : g.M - 1;
+            res[r] = R[mc * ldr + nc] * (RS ? RS[mc] : 1.f);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mrow + (r & 3) + 8 * (r >> 2);
+          if (m < g.M && n < g.N) Y[m * ldy + n] = R ? acc[i][j][r] + res[r] : acc[i][j][r];
+        }
+      }
+    }
+}
+
+// bf16x3 split path (gemm_x3.hip): exact-fp32-class results from six bf16 MFMAs per product block.
+bool pir_nn_x3_wanted(const pir_gemm_nn_t* a, int knob);
+int pir_nn_x3_launch(const pir_gemm_nn_t* a, int cfg, hipStream_t stream);

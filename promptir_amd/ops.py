@@ -71,6 +71,12 @@ class _TimedLib:
 
 lib = _TimedLib(_lib.lib)
 
+# A/B switches for development (tools/, tests): PIR_NN_X3 = 0 | 1 forces the fp32-MFMA / bf16x3 gemm_nn path
+import os as _os
+
+if _os.environ.get("PIR_NN_X3") is not None:
+    _lib.lib.pir_tune_set(3, int(_os.environ["PIR_NN_X3"]))
+
 
 # ----------------------------------------------------------------------------- plumbing
 def _require_gpu(*tensors: torch.Tensor) -> None:
@@ -129,8 +135,11 @@ def gemm_nn(A: torch.Tensor, a_batch: Tuple[int, int], a_sm: int, a_sk: int,
             Y: torch.Tensor, y_off: int, y_batch: Tuple[int, int], ldy: int,
             M: int, K: int, N: int, O1: int, O2: int,
             R: Optional[torch.Tensor] = None, r_off: int = 0, r_batch: Tuple[int, int] = (0, 0), ldr: int = 0,
-            rowscale: Optional[torch.Tensor] = None, rs_batch: Tuple[int, int] = (0, 0)) -> None:
+            rowscale: Optional[torch.Tensor] = None, rs_batch: Tuple[int, int] = (0, 0),
+            A3: Optional[torch.Tensor] = None, a3_kp: int = 0) -> None:
     g = _lib.GemmNN()
+    if A3 is not None:
+        g.A3, g.a3_kp = A3.data_ptr(), a3_kp
     g.A, g.a_s1, g.a_s2, g.a_sm, g.a_sk = A.data_ptr(), a_batch[0], a_batch[1], a_sm, a_sk
     g.X, g.x_s1, g.x_s2, g.ldx = X.data_ptr() + 4 * x_off, x_batch[0], x_batch[1], ldx
     g.Y, g.y_s1, g.y_s2, g.ldy = Y.data_ptr() + 4 * y_off, y_batch[0], y_batch[1], ldy
@@ -161,6 +170,44 @@ def gemm_nt(X: torch.Tensor, x_off: int, x_str: Tuple[int, int, int], ldx: int,
     check(lib.pir_gemm_nt(C.byref(g), _stream()), "pir_gemm_nt")
 
 
+# ---- bf16x3 weight pieces (pir_split_bf16x3), cached per weight tensor OBJECT and orientation.
+# Keyed weakly by the Parameter object (an address could be recycled by the allocator for another model's
+# weights); valid while (storage address, torch version counter, generation) are unchanged.  The version
+# counter covers load_state_dict and torch optimisers; the fused AdamW kernel writes through raw pointers,
+# which torch cannot see, so promptir_amd.train calls `weights_changed()` after every step (so must any
+# caller that edits weights through `.data` / raw pointers).
+import weakref as _weakref
+
+USE_X3 = _os.environ.get("PIR_X3", "1") != "0"
+_SPLIT = {}   # id(tensor) -> (weakref to the tensor, {dgrad: (validity, pieces)}); identity-keyed (tensor == is elementwise)
+_WEIGHT_GEN = [0]
+
+
+def weights_changed() -> None:
+    _WEIGHT_GEN[0] += 1
+
+
+def _split_weight(w: torch.Tensor, dgrad: bool):
+    cout, cin = w.shape[0], w.shape[1]
+    M, K, sm, sk = (cin, cout, 1, cin) if dgrad else (cout, cin, cin, 1)
+    kp = (K + 15) // 16 * 16
+    ver = (w.data_ptr(), w._version, _WEIGHT_GEN[0])
+    key = id(w)
+    rec = _SPLIT.get(key)
+    if rec is None or rec[0]() is not w:
+        rec = (_weakref.ref(w, lambda _r, _k=key: _SPLIT.pop(_k, None)), {})
+        _SPLIT[key] = rec
+    slot = rec[1]
+    ent = slot.get(dgrad)
+    if ent is not None and ent[0] == ver:
+        return ent[1], kp
+    buf = ent[1] if ent is not None and ent[1].device == w.device else \
+        torch.empty(3 * M * kp, dtype=torch.bfloat16, device=w.device)
+    check(lib.pir_split_bf16x3(w.data_ptr(), M, K, sm, sk, buf.data_ptr(), _stream()), "pir_split_bf16x3")
+    slot[dgrad] = (ver, buf)
+    return buf, kp
+
+
 def conv1x1_forward(x: torch.Tensor, w: torch.Tensor, residual: Optional[torch.Tensor] = None,
                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y[b] = W x[b] (+ residual[b]);  w is [Cout, Cin] or [Cout, Cin, 1, 1]."""
@@ -172,8 +219,9 @@ def conv1x1_forward(x: torch.Tensor, w: torch.Tensor, residual: Optional[torch.T
         out = torch.empty((b, cout, h, wd), dtype=torch.float32, device=x.device)
     if residual is not None:
         residual = _planes(residual)
+    a3, kp = _split_weight(w, dgrad=False) if USE_X3 else (None, 0)
     gemm_nn(w, (0, 0), cin, 1, x, 0, (_bs(x), 0), hw, out, 0, (_bs(out), 0), hw, cout, cin, hw, b, 1,
-            R=residual, r_batch=(_bs(residual), 0) if residual is not None else (0, 0), ldr=hw)
+            R=residual, r_batch=(_bs(residual), 0) if residual is not None else (0, 0), ldr=hw, A3=a3, a3_kp=kp)
     return out
 
 
@@ -185,7 +233,8 @@ def conv1x1_dgrad(dy: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor]
     hw = h * wd
     if out is None:
         out = torch.empty((b, cin, h, wd), dtype=torch.float32, device=dy.device)
-    gemm_nn(w, (0, 0), 1, cin, dy, 0, (_bs(dy), 0), hw, out, 0, (_bs(out), 0), hw, cin, cout, hw, b, 1)
+    a3, kp = _split_weight(w, dgrad=True) if USE_X3 else (None, 0)
+    gemm_nn(w, (0, 0), 1, cin, dy, 0, (_bs(dy), 0), hw, out, 0, (_bs(out), 0), hw, cin, cout, hw, b, 1, A3=a3, a3_kp=kp)
     return out
 
 

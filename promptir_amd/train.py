@@ -82,6 +82,7 @@ class FlatAdamW:
             ops.adamw_step(self.param, self.grad, self.exp_avg, self.exp_avg_sq, self.steps,
                            lr=self.lr if lr is None else lr, betas=self.betas, eps=self.eps,
                            weight_decay=self.weight_decay, grad_scale=grad_scale)
+            ops.weights_changed()   # cached bf16x3 weight pieces are stale now
         else:
             raise RuntimeError("FlatAdamW.step: the AdamW kernel is HIP-only (no CPU fallback)")
 
