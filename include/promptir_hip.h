@@ -38,7 +38,8 @@ int pir_abi_version(void);
 const char* pir_arch(void);
 
 /* tuning / A-B knob used by tools/ktune.py: knob 0 = gemm_nn tile config, 1 = gemm_nt tile config,
- * 2 = gemm_nt split count; value -1 (knobs 0,1) or 0 (knob 2) restores the built-in heuristic. */
+ * 2 = gemm_nt split count, 3 / 4 = force (1) or forbid (0) the bf16x3 matrix-core path of gemm_nn / gemm_nt;
+ * value -1 (0 for knob 2) restores the built-in policy. */
 int pir_tune_set(int knob, int value);
 
 /* ------------------------------------------------------------------ GEMM core

@@ -26,7 +26,7 @@ constexpr int BK = PIR_BK;  // k-depth of one LDS stage (PIR_BK/2 MFMA k-steps)
 constexpr bool PIN_SCHED = PIR_PIN_SCHED;
 
 // tuning overrides (pir_tune_set): -1 / 0 = automatic
-int g_nn_cfg = -1, g_nt_cfg = -1, g_nt_splits = 0, g_nn_x3 = -1;
+int g_nn_cfg = -1, g_nt_cfg = -1, g_nt_splits = 0, g_nn_x3 = -1, g_nt_x3 = -1;
 
 __device__ __forceinline__ int c_row(int reg, int lane) { return pir_c_row(reg, lane); }
 
@@ -476,6 +476,168 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_nt_kernel(NTParams p) {
     }
 }
 
+// gemm_nt on the bf16 matrix cores (bf16x3 split, see gemm_x3.hip): both operands are rows with the
+// contraction index (pixels) contiguous, so an MFMA fragment = 8 consecutive pixels of one row = two 16-byte
+// global loads, split into three bf16 pieces when the stage is written to LDS ([k-group][row][8 x bf16]).
+// One stage = 16 pixels = one v_mfma_f32_32x32x16_bf16 k-step; split-K, partial layout and the reduction
+// are those of gemm_nt_kernel.  Needs 16-byte aligned rows and N % 4 == 0 (else the fp32 kernel runs).
+constexpr int X3_BK = 16;
+
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_x3_kernel(NTParams p) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, T = WM * WN * 64;
+  constexpr int XKS = BM + 4, YKS = BN + 4;            // 16-byte units between the two k-groups
+  constexpr int XU = 2 * XKS, YU = 2 * YKS, PART = XU + YU, STAGE = 3 * PART;
+  __shared__ pir_bf16x8 smem[2 * STAGE];
+
+  const pir_gemm_nt_t& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int tiles_i = (g.M1 + BM - 1) / BM;
+  const int i0 = (blockIdx.x % tiles_i) * BM, j0 = (blockIdx.x / tiles_i) * BN;
+  const int split = blockIdx.y;
+  const int o = blockIdx.z, o1 = o / g.O2, o2 = o % g.O2;
+  const float* __restrict__ Xb = g.X + o1 * g.x_s1 + o2 * g.x_s2;
+  const float* __restrict__ Yb = g.Y + o1 * g.y_s1 + o2 * g.y_s2;
+
+  // the launcher sets chunks_per_r = ceil(N / 16) for this kernel
+  const long total = (long)g.BR * p.chunks_per_r;
+  const long per = (total + p.splits - 1) / p.splits;
+  const long c_begin = split * per, c_end = (c_begin + per < total) ? c_begin + per : total;
+
+  constexpr int XF = 2 * BM, NX = (XF + T - 1) / T;    // fragments (8 pixels of one row) per stage
+  constexpr int YF = 2 * BN, NY = (YF + T - 1) / T;
+  struct Stage { f32x4 x[NX][2]; f32x4 y[NY][2]; };
+
+  auto load = [&](long c, Stage& st) {
+    const int r = (int)(c / p.chunks_per_r);
+    const int nb = (int)(c % p.chunks_per_r) * X3_BK;
+    const float* __restrict__ Xp = Xb + r * g.x_sr;
+    const float* __restrict__ Yp = Yb + r * g.y_sr;
+#pragma unroll
+    for (int q = 0; q < NX; ++q) {
+      const int f = tid + q * T;
+      int kg = f & 1, ii = f >> 1;                      // the two k-groups of a row on adjacent lanes: 64 B per row
+      if (ii >= BM) { ii = 0; kg = 0; }
+      const int i = i0 + ii, ic = i < g.M1 ? i : g.M1 - 1;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int n = nb + 8 * kg + 4 * h, nc = n < g.N ? n : g.N - 4;
+        st.x[q][h] = *reinterpret_cast<const f32x4*>(Xp + ((long)ic * g.ldx + nc));
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NY; ++q) {
+      const int f = tid + q * T;
+      int kg = f & 1, jj = f >> 1;
+      if (jj >= BN) { jj = 0; kg = 0; }
+      const int j = j0 + jj, jc = j < g.M2 ? j : g.M2 - 1;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int n = nb + 8 * kg + 4 * h, nc = n < g.N ? n : g.N - 4;
+        st.y[q][h] = *reinterpret_cast<const f32x4*>(Yp + ((long)jc * g.ldy + nc));
+      }
+    }
+  };
+  auto stash = [&](int buf, long c, const Stage& st) {
+    pir_bf16x8* base = smem + buf * STAGE;
+    const int nb = (int)(c % p.chunks_per_r) * X3_BK;
+#pragma unroll
+    for (int q = 0; q < NX; ++q) {
+      const int f = tid + q * T;
+      const int kg = f & 1, ii = f >> 1;
+      if (XF % T == 0 || f < XF) {
+        const bool rok = i0 + ii < g.M1;
+        float v[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bool ok = rok && nb + 8 * kg + 4 * h < g.N;   // N % 4 == 0: a float4 is all-or-nothing
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[4 * h + e] = ok ? st.x[q][h][e] : 0.f;
+        }
+        const pir_frag3 fr = pir_split8(v);
+        const int u = kg * XKS + ii;
+        base[u] = fr.hi; base[PART + u] = fr.mid; base[2 * PART + u] = fr.lo;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NY; ++q) {
+      const int f = tid + q * T;
+      const int kg = f & 1, jj = f >> 1;
+      if (YF % T == 0 || f < YF) {
+        const bool rok = j0 + jj < g.M2;
+        float v[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bool ok = rok && nb + 8 * kg + 4 * h < g.N;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[4 * h + e] = ok ? st.y[q][h][e] : 0.f;
+        }
+        const pir_frag3 fr = pir_split8(v);
+        const int u = XU + kg * YKS + jj;
+        base[u] = fr.hi; base[PART + u] = fr.mid; base[2 * PART + u] = fr.lo;
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto compute = [&](int buf) {
+    const pir_bf16x8* base = smem + buf * STAGE;
+    const int h = lane >> 5, r = lane & 31;
+    const pir_bf16x8* xp = base + h * XKS + wm * TM * 32 + r;
+    const pir_bf16x8* yp = base + XU + h * YKS + wn * TN * 32 + r;
+    pir_bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { ah[i] = xp[i * 32]; am[i] = xp[PART + i * 32]; al[i] = xp[2 * PART + i * 32]; }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { bh[j] = yp[j * 32]; bm[j] = yp[PART + j * 32]; bl[j] = yp[2 * PART + j * 32]; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = pir_mfma_x3(ah[i], am[i], al[i], bh[j], bm[j], bl[j], acc[i][j]);
+  };
+
+  if (c_begin < c_end) {
+    Stage s0, s1;
+    load(c_begin, s0);
+    if (c_begin + 1 < c_end) load(c_begin + 1, s1);
+    stash(0, c_begin, s0);
+    __syncthreads();
+    long c = c_begin;
+    for (; c + 1 < c_end; c += 2) {
+      if (c + 2 < c_end) load(c + 2, s0);
+      compute(0);
+      stash(1, c + 1, s1);
+      __syncthreads();
+      if (c + 3 < c_end) load(c + 3, s1);
+      compute(1);
+      if (c + 2 < c_end) stash(0, c + 2, s0);
+      __syncthreads();
+    }
+    if (c < c_end) compute(0);
+  }
+
+  float* __restrict__ P = g.ws + ((long)split * (g.O1 * g.O2) + o) * ((long)g.M1 * g.M2);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int jj = j0 + (wn * TN + j) * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ii = i0 + (wm * TM + i) * 32 + c_row(r, lane);
+        if (ii < g.M1 && jj < g.M2) P[(long)ii * g.M2 + jj] = acc[i][j][r];
+      }
+    }
+}
+
 // G[o][i][j] (strided) = alpha * sum_s ws[s][o][i][j]  (+ G).  64 consecutive elements x GR split
 // groups per block; every thread sums its groups' splits with independent loads in flight, the
 // groups are combined through LDS in a fixed order (deterministic).
@@ -518,7 +680,7 @@ struct NTPlan {
   int splits, chunks_per_r;
 };
 
-NTPlan nt_plan(int M1, int M2, int N, int O, int BR) {
+NTPlan nt_plan(int M1, int M2, int N, int O, int BR, int bk = NT_BK) {
   NTPlan pl;
   if (g_nt_cfg >= 0) {
     pl.cfg = g_nt_cfg;
@@ -531,10 +693,11 @@ NTPlan nt_plan(int M1, int M2, int N, int O, int BR) {
     if (pad96 < pad128) { pl.cfg = 2; pl.bm = 128; pl.bn = 96; } else { pl.cfg = 3; pl.bm = 128; pl.bn = 128; }
   }
   const long tiles = pir_cdiv(M1, pl.bm) * pir_cdiv(M2, pl.bn) * O;
-  pl.chunks_per_r = (int)pir_cdiv(N, NT_BK);
+  pl.chunks_per_r = (int)pir_cdiv(N, bk);
   const long total = (long)BR * pl.chunks_per_r;
   long want = pir_cdiv(3L * PIR_NUM_CU, tiles);          // ~3 blocks per CU overall
-  long max_by_work = total / 16 > 0 ? total / 16 : 1;     // at least 16 stages (512 pixels) per split
+  const long min_stages = 512 / bk;                       // at least 512 pixels per split
+  long max_by_work = total / min_stages > 0 ? total / min_stages : 1;
   long s = want < max_by_work ? want : max_by_work;
   if (g_nt_splits > 0) s = g_nt_splits < total ? g_nt_splits : total;
   if (s < 1) s = 1;
@@ -557,6 +720,7 @@ extern "C" int pir_tune_set(int knob, int value) {
     case 1: g_nt_cfg = value; return PIR_OK;
     case 2: g_nt_splits = value; return PIR_OK;
     case 3: g_nn_x3 = value; return PIR_OK;
+    case 4: g_nt_x3 = value; return PIR_OK;
     default: return PIR_EINVAL;
   }
 }
@@ -599,7 +763,10 @@ extern "C" size_t pir_gemm_nt_ws_floats(int M1, int M2, int N, int O, int BR) {
   if (M1 <= 0 || M2 <= 0 || N <= 0 || O <= 0 || BR <= 0) return 0;
   // the launcher may swap the operands so that the larger extent plays M1: size for the worst of both
   NTPlan a = nt_plan(M1, M2, N, O, BR), b = nt_plan(M2, M1, N, O, BR);
+  NTPlan c = nt_plan(M1, M2, N, O, BR, X3_BK), d = nt_plan(M2, M1, N, O, BR, X3_BK);
   int s = a.splits > b.splits ? a.splits : b.splits;
+  if (c.splits > s) s = c.splits;
+  if (d.splits > s) s = d.splits;
   if (g_nt_splits > s) s = g_nt_splits;
   return (size_t)s * O * M1 * M2;
 }
@@ -625,22 +792,32 @@ extern "C" int pir_gemm_nt(const pir_gemm_nt_t* a, pir_stream_t stream) {
     v = g.g_si; g.g_si = g.g_sj; g.g_sj = v;
     int m = g.M1; g.M1 = g.M2; g.M2 = m;
   }
-  NTPlan pl = nt_plan(g.M1, g.M2, g.N, O, g.BR);
-  if ((size_t)pl.splits * O * g.M1 * g.M2 > a->ws_floats) return PIR_ENOMEM;
-  p.splits = pl.splits;
-  p.chunks_per_r = pl.chunks_per_r;
   hipStream_t s = (hipStream_t)stream;
   auto al = [](const float* q, long s1, long s2, long sr, long ld) {
     return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && s1 % 4 == 0 && s2 % 4 == 0 && sr % 4 == 0 && ld % 4 == 0;
   };
   const bool vec4 = g.H == 0 && g.N % 4 == 0 && al(g.X, g.x_s1, g.x_s2, g.x_sr, g.ldx) &&
                     al(g.Y, g.y_s1, g.y_s2, g.y_sr, g.ldy);
+  const bool x3 = vec4 && g_nt_x3 != 0;   // bf16x3 matrix-core path whenever rows are 16-byte aligned
+  NTPlan pl = nt_plan(g.M1, g.M2, g.N, O, g.BR, x3 ? X3_BK : NT_BK);
+  if ((size_t)pl.splits * O * g.M1 * g.M2 > a->ws_floats) return PIR_ENOMEM;
+  p.splits = pl.splits;
+  p.chunks_per_r = pl.chunks_per_r;
   dim3 grid((unsigned)(pir_cdiv(g.M1, pl.bm) * pir_cdiv(g.M2, pl.bn)), (unsigned)pl.splits, (unsigned)O);
-  switch (pl.cfg) {
-    case 0: launch_nt_cfg<2, 2, 1, 1, 4>(p, grid, vec4, s); break;
-    case 1: launch_nt_cfg<2, 2, 2, 1, 2>(p, grid, vec4, s); break;
-    case 2: launch_nt_cfg<2, 3, 2, 1, 2>(p, grid, vec4, s); break;
-    default: launch_nt_cfg<2, 2, 2, 2, 1>(p, grid, vec4, s); break;
+  if (x3) {
+    switch (pl.cfg) {
+      case 0: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 1, 2, 2>), grid, dim3(256), 0, s, p); break;   // 64 x 64
+      case 1: hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 1, 2, 2>), grid, dim3(256), 0, s, p); break;   // 128 x 64
+      case 2: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 3, 4, 1>), grid, dim3(256), 0, s, p); break;   // 128 x 96
+      default: hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p); break;  // 128 x 128
+    }
+  } else {
+    switch (pl.cfg) {
+      case 0: launch_nt_cfg<2, 2, 1, 1, 4>(p, grid, vec4, s); break;
+      case 1: launch_nt_cfg<2, 2, 2, 1, 2>(p, grid, vec4, s); break;
+      case 2: launch_nt_cfg<2, 3, 2, 1, 2>(p, grid, vec4, s); break;
+      default: launch_nt_cfg<2, 2, 2, 2, 1>(p, grid, vec4, s); break;
+    }
   }
   int st = pir_launch_status();
   if (st) return st;

@@ -59,6 +59,37 @@ __device__ __forceinline__ void pir_nn_epilogue(const f32x16 (&acc)[TM][TN], con
     }
 }
 
+// ---- bf16x3 split helpers (shared by gemm_x3.hip and the split-K gemm_nt in gemm.hip)
+typedef __bf16 pir_bf16x8 __attribute__((ext_vector_type(8)));
+struct pir_frag3 { pir_bf16x8 hi, mid, lo; };
+
+// exact three-way split of 8 fp32 values: x = hi + mid + lo (+ <= 2^-27 |x|), every subtraction exact
+__device__ __forceinline__ pir_frag3 pir_split8(const float (&v)[8]) {
+  pir_frag3 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = v[j];
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    f.hi[j] = h; f.mid[j] = m; f.lo[j] = (__bf16)r2;
+  }
+  return f;
+}
+
+// six-term product block: acc += (hi+mid+lo)_a x (hi+mid+lo)_b without the three <= 2^-27 terms
+__device__ __forceinline__ f32x16 pir_mfma_x3(const pir_bf16x8& ah, const pir_bf16x8& am, const pir_bf16x8& al,
+                                              const pir_bf16x8& bh, const pir_bf16x8& bm, const pir_bf16x8& bl, f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+  return c;
+}
+
 // bf16x3 split path (gemm_x3.hip): exact-fp32-class results from six bf16 MFMAs per product block.
 bool pir_nn_x3_wanted(const pir_gemm_nn_t* a, int knob);
 int pir_nn_x3_launch(const pir_gemm_nn_t* a, int cfg, hipStream_t stream);

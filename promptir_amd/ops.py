@@ -76,6 +76,8 @@ import os as _os
 
 if _os.environ.get("PIR_NN_X3") is not None:
     _lib.lib.pir_tune_set(3, int(_os.environ["PIR_NN_X3"]))
+if _os.environ.get("PIR_NT_X3") is not None:
+    _lib.lib.pir_tune_set(4, int(_os.environ["PIR_NT_X3"]))
 
 
 # ----------------------------------------------------------------------------- plumbing
