@@ -35,6 +35,35 @@ __device__ __forceinline__ void stage(float* lds, const float* __restrict__ plan
   }
 }
 
+// Register-staged variant: `stage_load` issues a tile's global loads into registers (zero for slots
+// outside the image), `stage_store` writes them to LDS later.  A persistent workgroup prefetches row tile
+// t+1 while it computes tile t.  MAXS bounds the slots per thread (checked on the host).
+template <int MAXS>
+__device__ __forceinline__ void stage_load(f32x4 (&regs)[MAXS], const float* __restrict__ plane, int H, int W, int row0,
+                                           int w0, int rows, int LPR, unsigned magic_spr) {
+  const int spr = LPR + 2, total = rows * spr;
+#pragma unroll
+  for (int i = 0; i < MAXS; ++i) {
+    const int s = threadIdx.x + i * blockDim.x;
+    const int lr = pir_fastdiv(s, magic_spr), j = s - lr * spr;
+    const int h = row0 + lr, col = w0 + (j - 1) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (s < total && h >= 0 && h < H && col >= 0 && col < W) v = *reinterpret_cast<const f32x4*>(plane + (long)h * W + col);
+    regs[i] = v;
+  }
+}
+template <int MAXS>
+__device__ __forceinline__ void stage_store(float* lds, const f32x4 (&regs)[MAXS], int rows, int LPR, int LS,
+                                            unsigned magic_spr) {
+  const int spr = LPR + 2, total = rows * spr;
+#pragma unroll
+  for (int i = 0; i < MAXS; ++i) {
+    const int s = threadIdx.x + i * blockDim.x;
+    const int lr = pir_fastdiv(s, magic_spr), j = s - lr * spr;
+    if (s < total) *reinterpret_cast<f32x4*>(lds + lr * LS + j * 4) = regs[i];
+  }
+}
+
 __device__ __forceinline__ void read6(const float* row, int o, float (&v)[6]) {
   v[0] = row[o - 1];
   const f32x4 m = *reinterpret_cast<const f32x4*>(row + o);
@@ -53,6 +82,8 @@ __device__ __forceinline__ void conv4(const float (&r0)[6], const float (&r1)[6]
   }
 }
 
+// PREFETCH: register-staged row tiles (pays when a plane has several row tiles); otherwise direct staging.
+template <bool PREFETCH>
 __global__ __launch_bounds__(256) void gdfn_dw_bwd_kernel(GArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float red[4 * 18];
@@ -81,12 +112,32 @@ __global__ __launch_bounds__(256) void gdfn_dw_bwd_kernel(GArgs a) {
 #pragma unroll
   for (int t = 0; t < 9; ++t) { ws1[t] = 0.f; ws2[t] = 0.f; f1[t] = k1[8 - t]; f2[t] = k2[8 - t]; }
 
+  constexpr int MAXS = 3;   // staging slots per thread and tile (host guarantees rows*(LPR+2) <= 3*threads)
+  const float* __restrict__ dgp = a.dg + b * a.dg_bs + c * HW;
+  f32x4 px1[MAXS], px2[MAXS], pdg[MAXS];
+  if (PREFETCH) {
+    stage_load<MAXS>(px1, x1p, a.H, a.W, -2, w0, RT + 4, LPR, a.magic_spr);
+    stage_load<MAXS>(px2, x2p, a.H, a.W, -2, w0, RT + 4, LPR, a.magic_spr);
+    stage_load<MAXS>(pdg, dgp, a.H, a.W, -1, w0, RT + 2, LPR, a.magic_spr);
+  }
+
   for (int tile_r = 0; tile_r < a.tiles_r; ++tile_r) {
   const int h0 = tile_r * RT;
   if (tile_r) __syncthreads();  // previous tile's phase 3 has finished reading LDS
-  stage(X1, x1p, a.H, a.W, h0 - 2, w0, RT + 4, LPR, LS, a.magic_spr);
-  stage(X2, x2p, a.H, a.W, h0 - 2, w0, RT + 4, LPR, LS, a.magic_spr);
-  stage(DG, a.dg + b * a.dg_bs + c * HW, a.H, a.W, h0 - 1, w0, RT + 2, LPR, LS, a.magic_spr);
+  if (!PREFETCH) {
+    stage(X1, x1p, a.H, a.W, h0 - 2, w0, RT + 4, LPR, LS, a.magic_spr);
+    stage(X2, x2p, a.H, a.W, h0 - 2, w0, RT + 4, LPR, LS, a.magic_spr);
+    stage(DG, dgp, a.H, a.W, h0 - 1, w0, RT + 2, LPR, LS, a.magic_spr);
+  } else {
+    stage_store<MAXS>(X1, px1, RT + 4, LPR, LS, a.magic_spr);
+    stage_store<MAXS>(X2, px2, RT + 4, LPR, LS, a.magic_spr);
+    stage_store<MAXS>(DG, pdg, RT + 2, LPR, LS, a.magic_spr);
+  }
+  if (PREFETCH && tile_r + 1 < a.tiles_r) {  // next row tile's loads fly during phases 2 and 3
+    stage_load<MAXS>(px1, x1p, a.H, a.W, h0 + RT - 2, w0, RT + 4, LPR, a.magic_spr);
+    stage_load<MAXS>(px2, x2p, a.H, a.W, h0 + RT - 2, w0, RT + 4, LPR, a.magic_spr);
+    stage_load<MAXS>(pdg, dgp, a.H, a.W, h0 + RT - 1, w0, RT + 2, LPR, a.magic_spr);
+  }
   __syncthreads();
 
   // ---- phase 2: t and dt on the halo-extended tile (rows h0-1 .. h0+RT, columns w0-1 .. w0+CT)
@@ -190,6 +241,7 @@ GPlan gplan(int H, int W) {
   p.threads = want >= 256 ? 256 : (int)(pir_cdiv(want, 64) * 64);
   if (p.threads < p.LPR) p.threads = (int)(pir_cdiv(p.LPR, 64) * 64);
   p.strips = p.threads / p.LPR;
+  if (p.strips > H) p.strips = H;
   const int LS = (p.LPR + 2) * 4;
   const int budget_rows = 13000 / LS;            // ~52 KB of LDS -> 3 workgroups per CU
   int rt_max = (budget_rows - 14) / 5;
@@ -199,6 +251,8 @@ GPlan gplan(int H, int W) {
   if (sr > 8) sr = 8;
   const int need = (int)pir_cdiv(H, p.strips);
   if (sr > need) sr = need;
+  // register staging holds at most 3 slots per thread: (RT+4)*(LPR+2) <= 3*threads
+  while (sr > 1 && (p.strips * sr + 4) * (p.LPR + 2) > 3 * p.threads) --sr;
   p.SR = sr;
   p.RT = p.strips * p.SR;
   p.tiles_r = (int)pir_cdiv(H, p.RT);
@@ -239,6 +293,7 @@ extern "C" int pir_gdfn_dwconv_bwd(const float* x, long x_bs, const float* w, co
   GPlan p = gplan(H, W);
   const long parts = (long)B * p.tiles_c;
   if ((size_t)parts * 2 * hid * 9 > ws_floats) return PIR_ENOMEM;
+  const bool prefetch = p.tiles_r > 1 && (p.RT + 4) * (p.LPR + 2) <= 3 * p.threads;
   if (p.lds_bytes > 64 * 1024) return PIR_EINVAL;
   GArgs a;
   a.x = x; a.x_bs = x_bs; a.w = w; a.dg = dg; a.dg_bs = dg_bs; a.dx = dx; a.dx_bs = dx_bs; a.ws = ws;
@@ -247,7 +302,10 @@ extern "C" int pir_gdfn_dwconv_bwd(const float* x, long x_bs, const float* w, co
   a.CT = p.CT; a.LPR = p.LPR; a.RT = p.RT; a.strips = p.strips; a.SR = p.SR; a.tiles_r = p.tiles_r; a.tiles_c = p.tiles_c;
   const long blocks = (long)B * hid * p.tiles_c;
   if (blocks > 2147483647L) return PIR_EINVAL;
-  hipLaunchKernelGGL(gdfn_dw_bwd_kernel, dim3((unsigned)blocks), dim3(p.threads), p.lds_bytes, (hipStream_t)stream, a);
+  if (prefetch)
+    hipLaunchKernelGGL(gdfn_dw_bwd_kernel<true>, dim3((unsigned)blocks), dim3(p.threads), p.lds_bytes, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(gdfn_dw_bwd_kernel<false>, dim3((unsigned)blocks), dim3(p.threads), p.lds_bytes, (hipStream_t)stream, a);
   int st = pir_launch_status();
   if (st) return st;
   return pir_reduce_partials(ws, 2L * hid * 9, (int)parts, 1.f, 0, dw, 2L * hid * 9, stream);
