@@ -208,6 +208,18 @@ int pir_prompt_mix_bwd(const float* dmix, const float* mix, const float* emb, co
                        float* dWl, float* dbl, float* dx, long dx_bs, int accumulate,
                        int B, int C, int L, int HW, pir_stream_t stream);
 
+/* ------------------------------------------------------------------ tiled inference (demo.py:17-48, test.py:100-104)
+ * Gather nth*ntw overlapping tile_h x tile_w tiles (start_i = min(i*stride, Hp - tile), demo.py:31-33) of an
+ * image logically padded at the bottom/right from HxW to HpxWp (pad_mode 0: F.pad 'reflect', demo.py:22;
+ * 1: flipped copy, test.py:102-103) into out[B*nth*ntw][C][tile_h][tile_w]. */
+int pir_tiles_gather(const float* img, long img_bs, float* out, int B, int C, int H, int W, int Hp, int Wp,
+                     int tile_h, int tile_w, int stride_h, int stride_w, int nth, int ntw, int pad_mode,
+                     pir_stream_t stream);
+/* out[b][c][y][x] = clamp01( sum of covering tiles / count ) for y<Hout, x<Wout (demo.py:37-47 + crop :126) */
+int pir_tiles_blend(const float* tiles, float* out, long out_bs, int B, int C, int Hp, int Wp,
+                    int tile_h, int tile_w, int stride_h, int stride_w, int nth, int ntw,
+                    int Hout, int Wout, int clamp01, pir_stream_t stream);
+
 /* ------------------------------------------------------------------ loss, copies, optimiser
  * nn.L1Loss() (train.py:32,43): loss = mean|a-b|; optional fused grad = sign(a-b)/count * gscale
  * (grad may be NULL). ws: 1024 floats. */

@@ -81,6 +81,8 @@ SIGNATURES = {
     "pir_prompt_resize_bwd_ws_floats": (Z, [I, I, I, I, I, I]),
     "pir_prompt_resize_bwd": (I, [P, L, P, P, P, P, P, Z, I, I, I, I, I, I, S]),
     "pir_prompt_mix_bwd": (I, [P, P, P, P, P, P, P, L, I, I, I, I, I, S]),
+    "pir_tiles_gather": (I, [P, L, P, I, I, I, I, I, I, I, I, I, I, I, I, I, S]),
+    "pir_tiles_blend": (I, [P, P, L, I, I, I, I, I, I, I, I, I, I, I, I, I, S]),
     "pir_l1_loss": (I, [P, P, P, P, F, P, L, S]),
     "pir_l1_loss_grad": (I, [P, P, P, P, L, S]),
     "pir_copy_planes": (I, [P, L, P, L, I, I, L, S]),
