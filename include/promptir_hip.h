@@ -229,6 +229,11 @@ int pir_l1_loss(const float* restored, const float* clean, float* loss, float* g
  * grad = sign(restored-clean) * dloss[0] / count */
 int pir_l1_loss_grad(const float* restored, const float* clean, const float* dloss, float* grad,
                      long count, pir_stream_t stream);
+/* GPU-side Gaussian degradation in the uint8 domain (utils/degradation_utils.py:21-27):
+ * out = uint8(clip(floor(clean*255) + N(0,1)*sigma[b], 0, 255)) / 255 with the counter-based generator of
+ * promptir_amd/weights.py (keys[2b], keys[2b+1] = the two Box-Muller stream keys of image b). */
+int pir_degrade_gaussian(const float* clean, float* out, const float* sigma, const unsigned long long* keys,
+                         long per_image, int B, pir_stream_t stream);
 /* y[b][c][n] = x[b][c][n] (+ y if accumulate) for channel-slice copies (torch.cat, net/model.py:341-370) */
 int pir_copy_planes(const float* x, long x_bs, float* y, long y_bs, int accumulate,
                     int B, long plane_floats, pir_stream_t stream);

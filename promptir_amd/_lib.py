@@ -85,6 +85,7 @@ SIGNATURES = {
     "pir_tiles_blend": (I, [P, P, L, I, I, I, I, I, I, I, I, I, I, I, I, I, S]),
     "pir_l1_loss": (I, [P, P, P, P, F, P, L, S]),
     "pir_l1_loss_grad": (I, [P, P, P, P, L, S]),
+    "pir_degrade_gaussian": (I, [P, P, P, P, L, I, S]),
     "pir_copy_planes": (I, [P, L, P, L, I, I, L, S]),
     "pir_add": (I, [P, P, P, L, S]),
     "pir_reduce_partials": (I, [P, L, I, F, I, P, L, S]),

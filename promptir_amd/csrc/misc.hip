@@ -115,6 +115,34 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// sigma-noise in the uint8 domain (reference utils/degradation_utils.py:21-27 / utils/dataset_utils.py:195-198:
+// np.clip(clean + randn * sigma, 0, 255).astype(np.uint8), then ToTensor) with the repo's counter-based
+// generator (promptir_amd/weights.py: splitmix64 -> uniform -> Box-Muller), so host and device agree.
+__device__ __forceinline__ float u01_splitmix(unsigned long long key, unsigned long long idx1) {
+  unsigned long long x = key + idx1 * 0x9E3779B97F4A7C15ULL;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+  x = x ^ (x >> 31);
+  return (float)(x >> 40) * 5.9604644775390625e-08f;  // 2^-24
+}
+
+__global__ __launch_bounds__(256) void degrade_gaussian_kernel(const float* __restrict__ clean, float* __restrict__ out,
+                                                               const float* __restrict__ sigma,
+                                                               const unsigned long long* __restrict__ keys, long per_image,
+                                                               int B) {
+  const long total = (long)B * per_image;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(e / per_image);
+    const unsigned long long i1 = (unsigned long long)(e % per_image) + 1ULL;
+    const double u1 = (double)u01_splitmix(keys[2 * b], i1), u2 = (double)u01_splitmix(keys[2 * b + 1], i1);
+    const float n = (float)(sqrt(-2.0 * log(1.0 - u1)) * cos(6.283185307179586476925 * u2));
+    const double img255 = floor((double)clean[e] * 255.0);
+    double v = img255 + (double)n * (double)sigma[b];
+    v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+    out[e] = (float)(unsigned char)v / 255.0f;
+  }
+}
+
 inline int grid_for(long total, int cap = 4096) { long g = pir_cdiv(total, 256); if (g < 1) g = 1; return (int)(g < cap ? g : cap); }
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -140,6 +168,14 @@ extern "C" int pir_l1_loss_grad(const float* restored, const float* clean, const
   PIR_CHECK_ARG(restored && clean && dloss && grad && count > 0);
   hipLaunchKernelGGL(l1_grad_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream,
                      restored, clean, dloss, 1.f / (float)count, grad, count);
+  return pir_launch_status();
+}
+
+extern "C" int pir_degrade_gaussian(const float* clean, float* out, const float* sigma, const unsigned long long* keys,
+                                    long per_image, int B, pir_stream_t stream) {
+  PIR_CHECK_ARG(clean && out && sigma && keys && per_image > 0 && B > 0);
+  hipLaunchKernelGGL(degrade_gaussian_kernel, dim3(grid_for((long)B * per_image)), dim3(256), 0, (hipStream_t)stream,
+                     clean, out, sigma, keys, per_image, B);
   return pir_launch_status();
 }
 
