@@ -60,13 +60,14 @@ typedef struct {
   const float* rowscale; long rs_s1, rs_s2;
   int M, K, N;
   int O1, O2;
-  /* optional: A pre-split into three bf16 pieces by pir_split_bf16x3 (layout [3][M][a3_kp], unbatched).
+  /* optional: A pre-split into three bf16 pieces by pir_split_bf16x3 (layout [3][a3_kp/16][M][16], unbatched).
    * When set, the bf16x3 matrix-core path reads it instead of splitting A on the fly. NULL otherwise. */
   const void* A3; int a3_kp;
 } pir_gemm_nn_t;
 int pir_gemm_nn(const pir_gemm_nn_t* args, pir_stream_t stream);
-/* out[part][m][k] (bf16, k padded with zeros to kp = multiple of 16) = part-th piece of the exact split
- * W(m,k) = hi + mid + lo with W(m,k) = W[m*sm + k*sk]; out holds 3*M*kp bf16. Used once per weight
+/* out[part][k/16][m][k%16] (bf16, k padded with zeros to kp = multiple of 16) = part-th piece of the exact
+ * split W(m,k) = hi + mid + lo with W(m,k) = W[m*sm + k*sk]; out holds 3*M*kp bf16.  The 16 k-values of one
+ * matrix-core k-step are contiguous per row and rows are contiguous per k-step. Used once per weight
  * tensor and step for the forward (sm=K, sk=1) and input-gradient (sm=1, sk=Cin) orientations. */
 size_t pir_split_bf16x3_bytes(int M, int K);
 int pir_split_bf16x3(const float* W, int M, int K, long sm, long sk, void* out, pir_stream_t stream);

@@ -17,6 +17,7 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int XK = 16;  // k-depth of one LDS stage = one bf16 MFMA k-step
 
 struct Frag3 { bf16x8 hi, mid, lo; };
@@ -57,27 +58,50 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_x3_kernel(pir_gemm_nn_t g
   constexpr int AF = 2 * BM, NA = (AF + T - 1) / T;   // 8-deep k fragments per stage
   constexpr int BF = 2 * BN, NB = (BF + T - 1) / T;
   struct Stage { float a[A_PRE ? 1 : NA][8]; bf16x8 a3[A_PRE ? NA : 1][3]; float b[NB][8]; };
-  const bf16x8* __restrict__ A3 = reinterpret_cast<const bf16x8*>(g.A3);
-  const long a3_part = (long)g.M * g.a3_kp / 8;   // 16-byte units per part
   const int iters = (g.K + XK - 1) / XK;
 
   // fragment -> (row, k-group).  k-fast A (forward weights): the two k-groups of a row sit on adjacent lanes
   auto a_map = [&](int f, int& mm, int& kg) { if (A_MFAST) { mm = f % BM; kg = f / BM; } else { kg = f & 1; mm = f >> 1; } };
 
-  auto load = [&](int it, Stage& st) {
+  // Buffer descriptors (wave-uniform): B rows beyond K and everything past the last valid element read as 0
+  // through the hardware range check, so the k tail needs no masks; per-lane offsets are computed once and
+  // each load adds a scalar row offset (no vector address arithmetic inside the k loop).
+  const __amdgpu_buffer_rsrc_t xrs = pir_make_rsrc(X, (unsigned)((((long)g.K - 1) * g.ldx + g.N) * 4));
+  const __amdgpu_buffer_rsrc_t ars = pir_make_rsrc(g.A3, A_PRE ? (unsigned)(6L * g.M * g.a3_kp) : 0u);
+  static_assert(BF % T == 0, "B fragments must tile the workgroup");
+  int b_voff[NB], b_kg[NB], a_voff[NA];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int f = tid + i * T;
+    b_voff[i] = (n0 + f % BN) * 4;
+    b_kg[i] = __builtin_amdgcn_readfirstlane(f / BN);   // BN is a multiple of 64: uniform per wave
+  }
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {   // pre-split A: lanes (2r, 2r+1) = the two k-groups of row r -> 1 KB contiguous per wave
+    const int f = tid + i * T;
+    int mm = f >> 1, kg = f & 1;
+    if (mm >= BM) { mm = 0; kg = 0; }
+    const int m = m0 + mm, mc = m < g.M ? m : g.M - 1;
+    a_voff[i] = (mc * 16 + 8 * kg) * 2;
+  }
+  const int a3_part_bytes = g.M * g.a3_kp * 2, a3_step_bytes = g.M * 32, ldx4 = (int)g.ldx * 4;
+
+  auto load = [&](int it_raw, Stage& st) {
+    const int it = it_raw < iters ? it_raw : iters - 1;
     const int k0 = it * XK, klast = g.K - 1 - k0;
     const float* __restrict__ At = A + (long)k0 * g.a_sk;
-    const float* __restrict__ Xt = X + (long)k0 * g.ldx;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      int mm, kg;
-      a_map(tid + i * T, mm, kg);
-      if (mm >= BM || kg > 1) { mm = 0; kg = 0; }
-      const int m = m0 + mm, mc = m < g.M ? m : g.M - 1;
       if (A_PRE) {  // [part][m][kp]: k is zero-padded to a multiple of 16, so no k clamp is needed
-        const long u = ((long)mc * g.a3_kp + k0 + 8 * kg) / 8;
-        st.a3[i][0] = A3[u]; st.a3[i][1] = A3[a3_part + u]; st.a3[i][2] = A3[2 * a3_part + u];
+#pragma unroll
+        for (int part = 0; part < 3; ++part)
+          st.a3[i][part] = __builtin_bit_cast(
+              bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ars, a_voff[i], part * a3_part_bytes + it * a3_step_bytes, 0));
       } else {
+        int mm, kg;
+        a_map(tid + i * T, mm, kg);
+        if (mm >= BM || kg > 1) { mm = 0; kg = 0; }
+        const int m = m0 + mm, mc = m < g.M ? m : g.M - 1;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int kk = 8 * kg + j, kc = kk <= klast ? kk : klast;
@@ -87,15 +111,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_x3_kernel(pir_gemm_nn_t g
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int f = tid + i * T;
-      int nn = f % BN, kg = f / BN;
-      if (kg > 1) { nn = 0; kg = 0; }
-      const int n = n0 + nn, nc = n < g.N ? n : g.N - 1;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int kk = 8 * kg + j, kc = kk <= klast ? kk : klast;
-        st.b[i][j] = Xt[kc * (int)g.ldx + nc];
-      }
+      for (int j = 0; j < 8; ++j)
+        st.b[i][j] = __builtin_bit_cast(
+            float, __builtin_amdgcn_raw_buffer_load_b32(xrs, b_voff[i], (k0 + 8 * b_kg[i] + j) * ldx4, 0));
     }
   };
 
@@ -106,7 +125,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_x3_kernel(pir_gemm_nn_t g
     for (int i = 0; i < NA; ++i) {
       const int f = tid + i * T;
       int mm, kg;
-      a_map(f, mm, kg);
+      if (A_PRE) { mm = f >> 1; kg = f & 1; } else a_map(f, mm, kg);
       if (AF % T == 0 || f < AF) {
         const int u = kg * AKS + mm;
         if (A_PRE) {  // rows beyond M only feed masked outputs: no zeroing needed
@@ -125,14 +144,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_x3_kernel(pir_gemm_nn_t g
     for (int i = 0; i < NB; ++i) {
       const int f = tid + i * T;
       const int nn = f % BN, kg = f / BN;
-      if (BF % T == 0 || f < BF) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (8 * kg + j <= klast) ? st.b[i][j] : 0.f;
-        const Frag3 fr = split8(v, true);
-        const int u = AU + kg * BN + nn;
-        base[u] = fr.hi; base[PART + u] = fr.mid; base[2 * PART + u] = fr.lo;
-      }
+      const Frag3 fr = split8(st.b[i], true);   // k tail already zero (range-checked loads)
+      const int u = AU + kg * BN + nn;
+      base[u] = fr.hi; base[PART + u] = fr.mid; base[2 * PART + u] = fr.lo;
     }
   };
 
@@ -169,6 +183,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_x3_kernel(pir_gemm_nn_t g
       }
   };
 
+  // Two stages are loaded ahead into registers.  (Measured: making these loads unconditional so that the
+  // compiler can keep exact vmcnt counts is slower - the two extra stage loads per tile cost more than the
+  // deeper prefetch gains, K is often only 3-6 stages.)
   Stage s0, s1;
   load(0, s0);
   if (iters > 1) load(1, s1);
@@ -190,6 +207,244 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_x3_kernel(pir_gemm_nn_t g
   pir_nn_epilogue<TM, TN>(acc, g, Y, o1, o2, m0, n0, wm, wn, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Ping-pong variant for pre-split weights (A3): one persistent 8-wave workgroup per CU, tile 128 x 256.
+// The two 4-wave halves ("ping": rows 0-63, "pong": rows 64-127 of the tile; each wave 64 x 64) alternate
+// between a matrix phase (24 MFMAs on the stage that is two steps old) and a staging phase (split the
+// freshly arrived fp32 activations to bf16x3, write them to a 3-deep LDS ring, issue the global loads of
+// four stages ahead, pre-read the next fragments).  The two workgroup barriers per k-step keep the halves
+// in opposite phases, so on every SIMD one wave feeds the matrix pipe while its partner does the VALU /
+// LDS / VMEM work.  The stage stream runs across tile boundaries (tiles b, b+G, ... of workgroup b), so the
+// loads of the next tile are in flight while the current one finishes: no per-tile prologue bubble.
+//
+// Activations are read with 16-byte loads along the pixel axis (one wave = one 1 KB row segment; per-lane
+// 4-byte gathers cost the same vector-memory issue slots for a quarter of the bytes and were the bottleneck),
+// stored row-major [k][pixel] in LDS and transposed into the k-contiguous MFMA B operand by
+// ds_read_b64_tr_b16 (cdna_hip_programming.md T10).
+constexpr int PP_BM = 128, PP_BN = 256;
+constexpr int PP_AKS = PP_BM + 4;                        // 16-byte units between the two k-groups of A
+constexpr int PP_BRS = PP_BN + 32;                       // B row stride (bf16): 576 B puts 4 rows on disjoint banks
+constexpr int PP_A_BYTES = 2 * PP_AKS * 16, PP_B_BYTES = 16 * PP_BRS * 2;
+constexpr int PP_PART_BYTES = PP_A_BYTES + PP_B_BYTES, PP_STAGE_BYTES = 3 * PP_PART_BYTES;
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+struct PPRegs { f32x4 b[2]; bf16x8 a[2]; };
+struct PPFrags { bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2]; };
+
+__device__ __forceinline__ void split4(const f32x4& v, bf16x4& hi, bf16x4& mid, bf16x4& lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float x = v[j];
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    hi[j] = h; mid[j] = m; lo[j] = (__bf16)r2;
+  }
+}
+
+// transposed 8-byte LDS read: lane i of each 16-lane group receives column i of the 4 rows addressed by the group
+__device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p, int row4_bytes) {
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + row4_bytes));
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+__global__ __launch_bounds__(512) void gemm_nn_pp_kernel(pir_gemm_nn_t g, int tiles_m, int tiles_n, int total) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * PP_STAGE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wid >> 2, wq = wid & 3, tg = tid & 255;
+  const int iters = (g.K + XK - 1) / XK;
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int my_tiles = (total - bid + G - 1) / G;
+  const int S = my_tiles * iters;
+  const int ldx4 = (int)g.ldx * 4;
+  const int a3_part_bytes = g.M * g.a3_kp * 2, a3_step_bytes = g.M * 32;
+  const __amdgpu_buffer_rsrc_t ars = pir_make_rsrc(g.A3, (unsigned)(6L * g.M * g.a3_kp));
+  const unsigned x_bytes = (unsigned)((((long)g.K - 1) * g.ldx + g.N) * 4);
+
+  // staging roles inside a half (256 threads): B rows 8*grp + wq and + 4 (one wave = one 256-pixel row);
+  // A: the half's own 64 rows, both k-groups (lanes 2r, 2r+1 = row r: a wave reads 1 KB contiguous);
+  // threads 0-127 carry parts hi and lo, threads 128-255 part mid
+  const int a_row = grp * 64 + ((tg & 127) >> 1), a_kg = tg & 1;
+  const int a_part0 = __builtin_amdgcn_readfirstlane(tg >> 7);   // 0 -> parts {0, 2}, 1 -> part {1}
+  const int b_row = 8 * grp + wq;
+
+  auto tile_coords = [&](int ord, int& m0, int& n0, int& o) __attribute__((always_inline)) {
+    const int t = pir_xcd_remap(ord * G + bid, total);
+    m0 = (t % tiles_m) * PP_BM;
+    const int rest = t / tiles_m;
+    n0 = (rest % tiles_n) * PP_BN;
+    o = rest / tiles_n;
+  };
+
+  // ---- load cursor
+  int l_ord = 0, l_k = 0, b_voff = 0, a_voff = 0;
+  __amdgpu_buffer_rsrc_t xrs = ars;
+  auto set_load_tile = [&](int ord) __attribute__((always_inline)) {
+    int m0, n0, o;
+    tile_coords(ord, m0, n0, o);
+    const int o1 = o / g.O2, o2 = o % g.O2;
+    xrs = pir_make_rsrc(g.X + o1 * g.x_s1 + o2 * g.x_s2, x_bytes);
+    b_voff = (n0 + lane * 4) * 4;
+    const int m = m0 + a_row, mc = m < g.M ? m : g.M - 1;
+    a_voff = (mc * 16 + 8 * a_kg) * 2;
+  };
+  set_load_tile(0);
+  // Unconditional on purpose (see gemm_nn_x3_kernel): past the last stage the cursor stays on it and the
+  // re-loaded data is never used, so the compiler can count the loads in flight exactly.
+  auto issue = [&](PPRegs& R) __attribute__((always_inline)) {
+    const int k0 = l_k * XK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      R.b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, b_voff, (k0 + b_row + 4 * i) * ldx4, 0));
+    R.a[0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                            ars, a_voff, a_part0 * a3_part_bytes + l_k * a3_step_bytes, 0));
+    R.a[1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                            ars, a_voff, 2 * a3_part_bytes + l_k * a3_step_bytes, 0));
+    if (l_k + 1 < iters) {
+      ++l_k;
+    } else if (l_ord + 1 < my_tiles) {
+      l_k = 0;
+      set_load_tile(++l_ord);
+    }
+  };
+  auto stash = [&](int buf, const PPRegs& R) __attribute__((always_inline)) {
+    unsigned char* base = smem + buf * PP_STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      bf16x4 hi, mid, lo;
+      split4(R.b[i], hi, mid, lo);
+      unsigned char* q = base + PP_A_BYTES + ((b_row + 4 * i) * PP_BRS + lane * 4) * 2;
+      *reinterpret_cast<bf16x4*>(q) = hi;
+      *reinterpret_cast<bf16x4*>(q + PP_PART_BYTES) = mid;
+      *reinterpret_cast<bf16x4*>(q + 2 * PP_PART_BYTES) = lo;
+    }
+    unsigned char* qa = base + (a_kg * PP_AKS + a_row) * 16;
+    if (a_part0 == 0) {
+      *reinterpret_cast<bf16x8*>(qa) = R.a[0];
+      *reinterpret_cast<bf16x8*>(qa + 2 * PP_PART_BYTES) = R.a[1];
+    } else {
+      *reinterpret_cast<bf16x8*>(qa + PP_PART_BYTES) = R.a[0];
+    }
+  };
+  const int fr_h = lane >> 5, fr_r = lane & 31;
+  const int tr_off = PP_A_BYTES + ((8 * fr_h + ((lane & 15) >> 2)) * PP_BRS + wq * 64 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  auto read_frags = [&](int buf, PPFrags& F) __attribute__((always_inline)) {
+    const unsigned char* base = smem + buf * PP_STAGE_BYTES;
+    const unsigned char* ap = base + (fr_h * PP_AKS + grp * 64 + fr_r) * 16;
+    const unsigned char* bp = base + tr_off;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      F.ah[i] = *reinterpret_cast<const bf16x8*>(ap + i * 512);
+      F.am[i] = *reinterpret_cast<const bf16x8*>(ap + PP_PART_BYTES + i * 512);
+      F.al[i] = *reinterpret_cast<const bf16x8*>(ap + 2 * PP_PART_BYTES + i * 512);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      F.bh[j] = tr_read8(bp + j * 64, 4 * PP_BRS * 2);
+      F.bm[j] = tr_read8(bp + PP_PART_BYTES + j * 64, 4 * PP_BRS * 2);
+      F.bl[j] = tr_read8(bp + 2 * PP_PART_BYTES + j * 64, 4 * PP_BRS * 2);
+    }
+  };
+
+  f32x16 acc[2][2];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  zero_acc();
+  int c_ord = 0, c_k = 0;
+  auto matrix_phase = [&](const PPFrags& F) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16 c = acc[i][j];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.al[i], F.bh[j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.ah[i], F.bl[j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.am[i], F.bm[j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.am[i], F.bh[j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.ah[i], F.bm[j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.ah[i], F.bh[j], c, 0, 0, 0);
+        acc[i][j] = c;
+      }
+    if (++c_k == iters && c_ord < my_tiles) {   // tile finished: store this half's 64 rows
+      int m0, n0, o;
+      tile_coords(c_ord, m0, n0, o);
+      const int o1 = o / g.O2, o2 = o % g.O2;
+      float* __restrict__ Y = g.Y + o1 * g.y_s1 + o2 * g.y_s2;
+      pir_nn_epilogue<2, 2>(acc, g, Y, o1, o2, m0 + grp * 64, n0, 0, wq, lane);
+      zero_acc();
+      c_k = 0;
+      ++c_ord;
+    }
+  };
+
+  PPRegs R0, R1, R2, R3;   // stage t travels in R[t & 3]: loaded 4 steps before it is staged, staged 2 before use
+  PPFrags F;
+  issue(R0); issue(R1);
+  stash(0, R0); stash(1, R1);
+  issue(R2); issue(R3); issue(R0); issue(R1);
+  __syncthreads();
+  int cbuf = 0, sbuf = 2;
+  auto advance = [&]() __attribute__((always_inline)) {
+    cbuf = cbuf == 2 ? 0 : cbuf + 1;
+    sbuf = sbuf == 2 ? 0 : sbuf + 1;
+  };
+  // the compiler may move MFMAs (register-only) across s_barrier, which would put both halves' matrix
+  // phases side by side: pin the phase boundaries
+  auto phase_barrier = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // The two halves run separate, branch-free step sequences (two barriers per step each, so the barrier
+  // counts match); steps go in fours so that the register sets are compile-time names; a stage count that
+  // is not a multiple of four just runs up to three dummy steps on stale data.
+  if (grp == 0) {
+    read_frags(0, F);
+    auto ping = [&](PPRegs& R) __attribute__((always_inline)) {
+      matrix_phase(F);
+      phase_barrier();
+      stash(sbuf, R);
+      issue(R);
+      read_frags(cbuf == 2 ? 0 : cbuf + 1, F);
+      phase_barrier();
+      advance();
+    };
+    for (int s = 0; s < S; s += 4) { ping(R2); ping(R3); ping(R0); ping(R1); }
+  } else {
+    auto pong = [&](PPRegs& R) __attribute__((always_inline)) {
+      stash(sbuf, R);
+      issue(R);
+      read_frags(cbuf, F);
+      phase_barrier();
+      matrix_phase(F);
+      phase_barrier();
+      advance();
+    };
+    for (int s = 0; s < S; s += 4) { pong(R2); pong(R3); pong(R0); pong(R1); }
+  }
+}
+
+int launch_pp(const pir_gemm_nn_t& g, hipStream_t s) {
+  const int tiles_m = (int)pir_cdiv(g.M, PP_BM), tiles_n = (int)pir_cdiv(g.N, PP_BN);
+  const long total = (long)tiles_m * tiles_n * g.O1 * g.O2;
+  const int grid = total < PIR_NUM_CU ? (int)total : PIR_NUM_CU;   // PIR_NUM_CU is a multiple of the XCD count
+  hipLaunchKernelGGL(gemm_nn_pp_kernel, dim3(grid), dim3(512), 0, s, g, tiles_m, tiles_n, (int)total);
+  return pir_launch_status();
+}
+
 template <int TM, int TN, int WM, int WN>
 int launch_cfg(const pir_gemm_nn_t& g, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -201,7 +456,9 @@ int launch_cfg(const pir_gemm_nn_t& g, hipStream_t s) {
   return pir_launch_status();
 }
 
-// out[part][m][k] bf16 pieces of W(m,k), zero-padded in k to kp
+// out[part][k/16][m][k%16] bf16 pieces of W(m,k), zero-padded in k to kp: the 16 k-values of one MFMA
+// k-step are contiguous per row and the rows of a tile are contiguous per k-step, so a tile's stage is ONE
+// contiguous block (BM x 32 bytes per part) that a wave reads with fully coalesced 16-byte loads.
 __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ W, int M, int K, long sm, long sk,
                                                            __bf16* __restrict__ out, int kp) {
   const long total = (long)M * kp;
@@ -212,7 +469,8 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
     const float r1 = x - (float)h;
     const __bf16 mid = (__bf16)r1;
     const float r2 = r1 - (float)mid;
-    out[e] = h; out[total + e] = mid; out[2 * total + e] = (__bf16)r2;
+    const long d = ((long)(k >> 4) * M + m) * 16 + (k & 15);
+    out[d] = h; out[total + d] = mid; out[2 * total + d] = (__bf16)r2;
   }
 }
 
@@ -245,6 +503,7 @@ int pir_nn_x3_launch(const pir_gemm_nn_t* a, int cfg, hipStream_t s) {
   const pir_gemm_nn_t& g = *a;
   const int M = g.M;
   const long batch = (long)g.O1 * g.O2;
+  if (cfg == 5 && g.A3) return launch_pp(g, s);
   if (cfg >= 0) {
     switch (cfg) {
       case 0: return launch_cfg<1, 2, 1, 4>(g, s);

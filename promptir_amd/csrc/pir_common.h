@@ -48,6 +48,15 @@ __device__ __forceinline__ void pir_gelu_both(float v, float& g, float& dg) {
   dg = cdf + v * pdf;
 }
 
+// Buffer descriptor over [base, base + bytes): the pointer halves go through readfirstlane so that the
+// descriptor is provably wave-uniform (otherwise every buffer op is wrapped in a waterfall loop).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pir_make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  void* p = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
 __device__ __forceinline__ float pir_wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Per-shape roofline of one instrumented train step: every pir_gemm_nn / pir_gemm_nt call with its
+shape, measured time, and the time its own roofline allows (bf16x3 MFMA ceiling and HBM ceiling)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from promptir_amd import ops  # noqa: E402
+from promptir_amd.train import DataParallelTrainer  # noqa: E402
+
+MFMA = 2500e12 / 6
+HBM = 6.3e12   # achievable (MI355X_MICROARCH.md)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--top", type=int, default=40)
+args = ap.parse_args()
+
+dev = torch.device("cuda", 0)
+net, sd = bench.build_model(dev)
+tr = DataParallelTrainer(net, lr=2e-4)
+x, t = bench.build_batch(args.batch, 128, 0, dev)
+for _ in range(2):
+    tr.train_step(x, t)
+torch.cuda.synchronize()
+
+shapes = []
+raw = ops.lib._raw
+orig_nn, orig_nt = raw.pir_gemm_nn, raw.pir_gemm_nt
+
+
+class Spy:
+    def __init__(self, fn, kind):
+        self.fn, self.kind = fn, kind
+
+    def __call__(self, *a):
+        g = a[0]._obj
+        if self.kind == "nn":
+            key = ("nn", g.M, g.K, g.N, g.O1 * g.O2, bool(g.R), bool(g.A3), int(g.a_sm == 1))
+            flops = 2.0 * g.M * g.K * g.N * g.O1 * g.O2
+            wshared = g.a_s1 == 0 and g.a_s2 == 0
+            byts = 4.0 * g.O1 * g.O2 * (g.K * g.N + g.M * g.N * (2 if g.R else 1)) + 4.0 * g.M * g.K * (1 if wshared else g.O1 * g.O2)
+        else:
+            key = ("nt", g.M1, g.M2, g.N, g.O1 * g.O2, g.BR, 0, 0)
+            flops = 2.0 * g.M1 * g.M2 * g.N * g.O1 * g.O2 * g.BR
+            byts = 4.0 * g.O1 * g.O2 * g.BR * (g.M1 + g.M2) * g.N
+        shapes.append((key, flops, byts))
+        return self.fn(*a)
+
+
+raw.pir_gemm_nn, raw.pir_gemm_nt = Spy(orig_nn, "nn"), Spy(orig_nt, "nt")
+ops.lib.start_timing()
+tr.train_step(x, t)
+recs = [r for r in ops.lib.stop_timing() if r[0] in ("pir_gemm_nn", "pir_gemm_nt")]
+raw.pir_gemm_nn, raw.pir_gemm_nt = orig_nn, orig_nt
+assert len(recs) == len(shapes), (len(recs), len(shapes))
+agg = {}
+for (name, sec, _), (key, flops, byts) in zip(recs, shapes):
+    a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
+    a[0] += 1; a[1] += sec; a[2] += flops; a[3] += byts
+tot = {"nn": [0.0, 0.0], "nt": [0.0, 0.0]}
+print(f"{'kind':3} {'M':>5} {'K':>5} {'N':>6} {'bat':>4} R A3 mf | calls  time_us  bound_us  mfma_us  hbm_us  eff")
+rows = []
+for key, (calls, sec, flops, byts) in agg.items():
+    tm, th = flops / MFMA, byts / HBM
+    bound = max(tm, th)
+    tot[key[0]][0] += sec; tot[key[0]][1] += bound
+    rows.append((sec - bound, key, calls, sec, bound, tm, th))
+for slack, key, calls, sec, bound, tm, th in sorted(rows, reverse=True)[: args.top]:
+    print(f"{key[0]:3} {key[1]:5d} {key[2]:5d} {key[3]:6d} {key[4]:4d} {int(key[5]):1d} {int(key[6]):2d} {key[7]:2d} | {calls:5d} "
+          f"{sec * 1e6:8.0f} {bound * 1e6:8.0f} {tm * 1e6:8.0f} {th * 1e6:8.0f} {bound / sec:5.2f}")
+for k, (sec, bound) in tot.items():
+    print(f"TOTAL {k}: measured {sec * 1e3:.2f} ms, roofline bound {bound * 1e3:.2f} ms, eff {bound / max(sec, 1e-12):.2f}")
