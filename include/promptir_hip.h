@@ -109,6 +109,16 @@ typedef struct {
 size_t pir_gemm_nt_ws_floats(int M1, int M2, int N, int O, int BR);
 int pir_gemm_nt(const pir_gemm_nt_t* args, pir_stream_t stream);
 
+/* Weight gradient of the dense 3x3 convolutions (pir_conv3x3) in one call:
+ *   dw[co][ci][dh+1][dw+1] (+)= sum_{b,h,w} dy[b][co][h][w] * x[b][ci][h+dh][w+dw]   (zero padding)
+ * = what autograd derives for OverlapPatchEmbed.proj, Down/Upsample.body[0], PromptGenBlock.conv3x3 and
+ * PromptIR.output (net/model.py:206,164,174,223,320).  One bf16x3 matrix-core launch with nine virtual
+ * shifted rows per channel when W % 8 == 0 and the planes are 16-byte aligned; nine shifted pir_gemm_nt
+ * launches otherwise.  ws holds pir_conv3x3_wgrad_ws_floats() floats. */
+size_t pir_conv3x3_wgrad_ws_floats(int Cout, int Cin, int H, int W, int B);
+int pir_conv3x3_wgrad(const float* dy, long dy_bs, const float* x, long x_bs, float* dw, int B, int Cout, int Cin,
+                      int H, int W, float* ws, size_t ws_floats, int accumulate, pir_stream_t stream);
+
 /* ------------------------------------------------------------------ LayerNorm over channels
  * net/model.py:47-76 (WithBias, :60-63) and :27-41 (BiasFree, :39-41), applied per pixel over
  * the channel axis of an NCHW tensor (to_3d / to_4d, :21-25).  eps = 1e-5 inside the sqrt,

@@ -58,6 +58,8 @@ SIGNATURES = {
     "pir_conv3x3": (I, [P, L, L, L, I, P, L, P, L, P, L, I, I, I, I, I, S]),
     "pir_gemm_nt_ws_floats": (Z, [I, I, I, I, I]),
     "pir_gemm_nt": (I, [C.POINTER(GemmNT), S]),
+    "pir_conv3x3_wgrad_ws_floats": (Z, [I, I, I, I, I]),
+    "pir_conv3x3_wgrad": (I, [P, L, P, L, P, I, I, I, I, I, P, Z, I, S]),
     "pir_layernorm_fwd": (I, [P, L, P, P, P, L, P, P, I, I, I, S]),
     "pir_layernorm_bwd_ws_floats": (Z, [I, I, I]),
     "pir_layernorm_bwd": (I, [P, L, P, L, P, I, P, P, P, L, P, L, P, P, P, Z, I, I, I, S]),

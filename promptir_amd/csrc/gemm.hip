@@ -301,6 +301,10 @@ struct NTParams {
   pir_gemm_nt_t g;
   int splits;        // split-K factor over the flattened (r, n-chunk) axis
   int chunks_per_r;  // ceil(N / NT_BK)
+  // dense-3x3 weight gradient in ONE launch (gemm_nt_x3_kernel<..., true>): the Y operand has M2 = 9*C virtual
+  // rows, row j = channel j/9 shifted by tap j%9 (times tap_sign); g.H x g.W is the image, W % 8 == 0
+  int tap_sign;
+  unsigned magic_w;
 };
 
 // WK waves of a block share an output tile and each takes a slice of every stage's k-range.
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_nt_kernel(NTParams p) {
 // are those of gemm_nt_kernel.  Needs 16-byte aligned rows and N % 4 == 0 (else the fp32 kernel runs).
 constexpr int X3_BK = 16;
 
-template <int TM, int TN, int WM, int WN>
+template <int TM, int TN, int WM, int WN, bool TAPS = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_x3_kernel(NTParams p) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, T = WM * WN * 64;
   constexpr int XKS = BM + 4, YKS = BN + 4;            // 16-byte units between the two k-groups
@@ -507,7 +511,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_x3_kernel(NTParams p) {
 
   constexpr int XF = 2 * BM, NX = (XF + T - 1) / T;    // fragments (8 pixels of one row) per stage
   constexpr int YF = 2 * BN, NY = (YF + T - 1) / T;
-  struct Stage { f32x4 x[NX][2]; f32x4 y[NY][2]; };
+  struct Stage { f32x4 x[NX][2]; f32x4 y[NY][2]; float ye[TAPS ? NY : 1]; };
 
   auto load = [&](long c, Stage& st) {
     const int r = (int)(c / p.chunks_per_r);
@@ -532,10 +536,27 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_x3_kernel(NTParams p) {
       int kg = f & 1, jj = f >> 1;
       if (jj >= BN) { jj = 0; kg = 0; }
       const int j = j0 + jj, jc = j < g.M2 ? j : g.M2 - 1;
+      if (TAPS) {
+        // virtual row jc = channel jc/9 seen through tap jc%9: the 8 pixels of a fragment lie in one image row
+        // (W % 8 == 0); two aligned float4 of the shifted row plus the one element that slides in from the side
+        const int ch = jc / 9, tap = jc - 9 * ch;
+        const int dh = p.tap_sign * (tap / 3 - 1), dw = p.tap_sign * (tap % 3 - 1);
+        const int n = nb + 8 * kg, nc = n < g.N ? n : g.N - 8;
+        const int hh = pir_fastdiv(nc, p.magic_w), w0 = nc - hh * g.W;
+        const int hs = hh + dh;
+        const bool rok = hs >= 0 && hs < g.H;
+        const float* __restrict__ row = Yp + ((long)ch * g.ldy + (rok ? hs : hh) * g.W);
+        st.y[q][0] = *reinterpret_cast<const f32x4*>(row + w0);
+        st.y[q][1] = *reinterpret_cast<const f32x4*>(row + w0 + 4);
+        const int we = dw < 0 ? w0 - 1 : w0 + 8;
+        const bool eok = we >= 0 && we < g.W;
+        st.ye[q] = row[eok ? we : w0];
+      } else {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int n = nb + 8 * kg + 4 * h, nc = n < g.N ? n : g.N - 4;
-        st.y[q][h] = *reinterpret_cast<const f32x4*>(Yp + ((long)jc * g.ldy + nc));
+        for (int h = 0; h < 2; ++h) {
+          const int n = nb + 8 * kg + 4 * h, nc = n < g.N ? n : g.N - 4;
+          st.y[q][h] = *reinterpret_cast<const f32x4*>(Yp + ((long)jc * g.ldy + nc));
+        }
       }
     }
   };
@@ -567,11 +588,31 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_x3_kernel(NTParams p) {
       if (YF % T == 0 || f < YF) {
         const bool rok = j0 + jj < g.M2;
         float v[8];
+        if (TAPS) {
+          const int j = j0 + jj, jc = j < g.M2 ? j : g.M2 - 1;
+          const int ch = jc / 9, tap = jc - 9 * ch;
+          const int dh = p.tap_sign * (tap / 3 - 1), dw = p.tap_sign * (tap % 3 - 1);
+          const int n = nb + 8 * kg;
+          const int hh = pir_fastdiv(n < g.N ? n : g.N - 8, p.magic_w), w0 = (n < g.N ? n : g.N - 8) - hh * g.W;
+          const bool ok = rok && n < g.N && hh + dh >= 0 && hh + dh < g.H;
+          const int we = dw < 0 ? w0 - 1 : w0 + 8;
+          const float ext = (we >= 0 && we < g.W) ? st.ye[q] : 0.f;
+          float a[8];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const bool ok = rok && nb + 8 * kg + 4 * h < g.N;
+          for (int e = 0; e < 4; ++e) { a[e] = st.y[q][0][e]; a[4 + e] = st.y[q][1][e]; }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[4 * h + e] = ok ? st.y[q][h][e] : 0.f;
+          for (int e = 0; e < 8; ++e) {
+            const float left = e == 0 ? ext : a[e - 1], right = e == 7 ? ext : a[e + 1];
+            const float val = dw == 0 ? a[e] : (dw < 0 ? left : right);
+            v[e] = ok ? val : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const bool ok = rok && nb + 8 * kg + 4 * h < g.N;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * h + e] = ok ? st.y[q][h][e] : 0.f;
+          }
         }
         const pir_frag3 fr = pir_split8(v);
         const int u = XU + kg * YKS + jj;
@@ -644,7 +685,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_x3_kernel(NTParams p) {
 template <int GR>
 __global__ __launch_bounds__(64 * GR) void nt_reduce_kernel(const float* __restrict__ ws, int splits, long per_split,
                                                             int M1, int M2, float* __restrict__ G, long g_so,
-                                                            long g_si, long g_sj, float alpha, int accumulate) {
+                                                            long g_si, long g_sj, float alpha, int accumulate,
+                                                            long g_st = 0) {
   __shared__ float red[GR][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const long e = blockIdx.x * 64L + lane;
@@ -668,7 +710,8 @@ __global__ __launch_bounds__(64 * GR) void nt_reduce_kernel(const float* __restr
     const long o = e / ((long)M1 * M2);
     const long ij = e % ((long)M1 * M2);
     const long i = ij / M2, j = ij % M2;
-    float* dst = G + o * g_so + i * g_si + j * g_sj;
+    // g_st != 0: j enumerates (channel, tap) pairs, channel stride g_sj and tap stride g_st
+    float* dst = g_st ? G + o * g_so + i * g_si + (j / 9) * g_sj + (j % 9) * g_st : G + o * g_so + i * g_si + j * g_sj;
     const float v = alpha * s;
     *dst = accumulate ? *dst + v : v;
   }
@@ -710,6 +753,59 @@ template <int TM, int TN, int WM, int WN, int WK>
 void launch_nt_cfg(const NTParams& p, dim3 grid, bool vec4, hipStream_t s) {
   if (vec4) hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, WK, 4>), grid, dim3(WM * WN * WK * 64), 0, s, p);
   else hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, WK, 1>), grid, dim3(WM * WN * WK * 64), 0, s, p);
+}
+
+// shared launcher of pir_gemm_nt and pir_conv3x3_wgrad: tile plan, split-K kernel, deterministic reduction
+int launch_nt(NTParams& p, size_t ws_floats, int tap_sign, long g_st, hipStream_t s) {
+  pir_gemm_nt_t& g = p.g;
+  const int O = g.O1 * g.O2;
+  auto al = [](const float* q, long s1, long s2, long sr, long ld) {
+    return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && s1 % 4 == 0 && s2 % 4 == 0 && sr % 4 == 0 && ld % 4 == 0;
+  };
+  const bool vec4 = (g.H == 0 || tap_sign != 0) && g.N % 4 == 0 && al(g.X, g.x_s1, g.x_s2, g.x_sr, g.ldx) &&
+                    al(g.Y, g.y_s1, g.y_s2, g.y_sr, g.ldy);
+  const bool x3 = vec4 && (g_nt_x3 != 0 || tap_sign != 0);   // bf16x3 matrix-core path whenever rows are 16-byte aligned
+  if (tap_sign != 0 && !x3) return PIR_EINVAL;
+  NTPlan pl = nt_plan(g.M1, g.M2, g.N, O, g.BR, x3 ? X3_BK : NT_BK);
+  if ((size_t)pl.splits * O * g.M1 * g.M2 > ws_floats) return PIR_ENOMEM;
+  p.splits = pl.splits;
+  p.chunks_per_r = pl.chunks_per_r;
+  p.tap_sign = tap_sign;
+  p.magic_w = pir_magic(g.W > 0 ? (unsigned)g.W : 1u);
+  dim3 grid((unsigned)(pir_cdiv(g.M1, pl.bm) * pir_cdiv(g.M2, pl.bn)), (unsigned)pl.splits, (unsigned)O);
+  if (tap_sign != 0) {
+    switch (pl.cfg) {
+      case 0: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 1, 2, 2, true>), grid, dim3(256), 0, s, p); break;
+      case 1: hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 1, 2, 2, true>), grid, dim3(256), 0, s, p); break;
+      case 2: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 3, 4, 1, true>), grid, dim3(256), 0, s, p); break;
+      default: hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2, 2, 2, true>), grid, dim3(256), 0, s, p); break;
+    }
+  } else if (x3) {
+    switch (pl.cfg) {
+      case 0: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 1, 2, 2>), grid, dim3(256), 0, s, p); break;   // 64 x 64
+      case 1: hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 1, 2, 2>), grid, dim3(256), 0, s, p); break;   // 128 x 64
+      case 2: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 3, 4, 1>), grid, dim3(256), 0, s, p); break;   // 128 x 96
+      default: hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p); break;  // 128 x 128
+    }
+  } else {
+    switch (pl.cfg) {
+      case 0: launch_nt_cfg<2, 2, 1, 1, 4>(p, grid, vec4, s); break;
+      case 1: launch_nt_cfg<2, 2, 2, 1, 2>(p, grid, vec4, s); break;
+      case 2: launch_nt_cfg<2, 3, 2, 1, 2>(p, grid, vec4, s); break;
+      default: launch_nt_cfg<2, 2, 2, 2, 1>(p, grid, vec4, s); break;
+    }
+  }
+  int st = pir_launch_status();
+  if (st) return st;
+  const long per_split = (long)O * g.M1 * g.M2;
+  const unsigned blocks = (unsigned)pir_cdiv(per_split, 64);
+  if (pl.splits >= 64)
+    hipLaunchKernelGGL((nt_reduce_kernel<16>), dim3(blocks), dim3(1024), 0, s, g.ws, pl.splits, per_split, g.M1, g.M2,
+                       g.G, g.g_so, g.g_si, g.g_sj, g.alpha, g.accumulate, g_st);
+  else
+    hipLaunchKernelGGL((nt_reduce_kernel<4>), dim3(blocks), dim3(256), 0, s, g.ws, pl.splits, per_split, g.M1, g.M2,
+                       g.G, g.g_so, g.g_si, g.g_sj, g.alpha, g.accumulate, g_st);
+  return pir_launch_status();
 }
 
 }  // namespace
@@ -792,42 +888,54 @@ extern "C" int pir_gemm_nt(const pir_gemm_nt_t* a, pir_stream_t stream) {
     v = g.g_si; g.g_si = g.g_sj; g.g_sj = v;
     int m = g.M1; g.M1 = g.M2; g.M2 = m;
   }
-  hipStream_t s = (hipStream_t)stream;
-  auto al = [](const float* q, long s1, long s2, long sr, long ld) {
-    return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && s1 % 4 == 0 && s2 % 4 == 0 && sr % 4 == 0 && ld % 4 == 0;
-  };
-  const bool vec4 = g.H == 0 && g.N % 4 == 0 && al(g.X, g.x_s1, g.x_s2, g.x_sr, g.ldx) &&
-                    al(g.Y, g.y_s1, g.y_s2, g.y_sr, g.ldy);
-  const bool x3 = vec4 && g_nt_x3 != 0;   // bf16x3 matrix-core path whenever rows are 16-byte aligned
-  NTPlan pl = nt_plan(g.M1, g.M2, g.N, O, g.BR, x3 ? X3_BK : NT_BK);
-  if ((size_t)pl.splits * O * g.M1 * g.M2 > a->ws_floats) return PIR_ENOMEM;
-  p.splits = pl.splits;
-  p.chunks_per_r = pl.chunks_per_r;
-  dim3 grid((unsigned)(pir_cdiv(g.M1, pl.bm) * pir_cdiv(g.M2, pl.bn)), (unsigned)pl.splits, (unsigned)O);
-  if (x3) {
-    switch (pl.cfg) {
-      case 0: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 1, 2, 2>), grid, dim3(256), 0, s, p); break;   // 64 x 64
-      case 1: hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 1, 2, 2>), grid, dim3(256), 0, s, p); break;   // 128 x 64
-      case 2: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 3, 4, 1>), grid, dim3(256), 0, s, p); break;   // 128 x 96
-      default: hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p); break;  // 128 x 128
+  return launch_nt(p, a->ws_floats, 0, 0L, (hipStream_t)stream);
+}
+
+// Dense 3x3 weight gradient in one launch: dW[co][ci][tap] = sum_{b,p} dy[b][co][p] * x[b][ci][p + s(tap)].
+// The operand with fewer channels is expanded to 9 virtual (shifted) rows per channel inside the bf16x3
+// gemm_nt kernel, so both tensors are read once from HBM instead of nine times.
+extern "C" size_t pir_conv3x3_wgrad_ws_floats(int Cout, int Cin, int H, int W, int B) {
+  if (Cout <= 0 || Cin <= 0 || H <= 0 || W <= 0 || B <= 0) return 0;
+  const int big = Cout > Cin ? Cout : Cin, small = Cout > Cin ? Cin : Cout;
+  NTPlan a = nt_plan(big, 9 * small, H * W, 1, B, X3_BK);
+  const size_t fused = (size_t)a.splits * big * 9 * small;
+  const size_t per_tap = pir_gemm_nt_ws_floats(Cout, Cin, H * W, 1, B);
+  return fused > per_tap ? fused : per_tap;
+}
+
+extern "C" int pir_conv3x3_wgrad(const float* dy, long dy_bs, const float* x, long x_bs, float* dw, int B, int Cout, int Cin,
+                                 int H, int W, float* ws, size_t ws_floats, int accumulate, pir_stream_t stream) {
+  PIR_CHECK_ARG(dy && x && dw && ws && B > 0 && Cout > 0 && Cin > 0 && H > 0 && W > 0);
+  const int HW = H * W;
+  NTParams p;
+  pir_gemm_nt_t& g = p.g;
+  g.O1 = 1; g.O2 = 1; g.BR = B; g.N = HW; g.H = H; g.W = W; g.shift_dh = 0; g.shift_dw = 0;
+  g.x_s1 = g.x_s2 = g.y_s1 = g.y_s2 = 0; g.g_so = 0;
+  g.G = dw; g.ws = ws; g.ws_floats = ws_floats; g.alpha = 1.f; g.accumulate = accumulate;
+  const bool fusable = W % 8 == 0 && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) & 15) == 0 &&
+                       dy_bs % 4 == 0 && x_bs % 4 == 0;
+  if (fusable) {
+    long g_st = 0;
+    int sign;
+    if (Cin <= Cout) {   // rows: dy channels; virtual rows: (ci, tap) reading x[p + s]
+      g.X = dy; g.x_sr = dy_bs; g.ldx = HW; g.M1 = Cout;
+      g.Y = x; g.y_sr = x_bs; g.ldy = HW; g.M2 = 9 * Cin;
+      g.g_si = (long)Cin * 9; g.g_sj = 1; sign = 1;
+    } else {             // rows: x channels; virtual rows: (co, tap) reading dy[q - s]
+      g.X = x; g.x_sr = x_bs; g.ldx = HW; g.M1 = Cin;
+      g.Y = dy; g.y_sr = dy_bs; g.ldy = HW; g.M2 = 9 * Cout;
+      g.g_si = 9; g.g_sj = (long)Cin * 9; g_st = 1; sign = -1;
     }
-  } else {
-    switch (pl.cfg) {
-      case 0: launch_nt_cfg<2, 2, 1, 1, 4>(p, grid, vec4, s); break;
-      case 1: launch_nt_cfg<2, 2, 2, 1, 2>(p, grid, vec4, s); break;
-      case 2: launch_nt_cfg<2, 3, 2, 1, 2>(p, grid, vec4, s); break;
-      default: launch_nt_cfg<2, 2, 2, 2, 1>(p, grid, vec4, s); break;
-    }
+    return launch_nt(p, ws_floats, sign, g_st, (hipStream_t)stream);
   }
-  int st = pir_launch_status();
-  if (st) return st;
-  const long per_split = (long)O * g.M1 * g.M2;
-  const unsigned blocks = (unsigned)pir_cdiv(per_split, 64);
-  if (pl.splits >= 64)
-    hipLaunchKernelGGL((nt_reduce_kernel<16>), dim3(blocks), dim3(1024), 0, s, a->ws, pl.splits, per_split, g.M1, g.M2,
-                       g.G, g.g_so, g.g_si, g.g_sj, g.alpha, g.accumulate);
-  else
-    hipLaunchKernelGGL((nt_reduce_kernel<4>), dim3(blocks), dim3(256), 0, s, a->ws, pl.splits, per_split, g.M1, g.M2,
-                       g.G, g.g_so, g.g_si, g.g_sj, g.alpha, g.accumulate);
-  return pir_launch_status();
+  // general fallback (W % 8 != 0 or unaligned planes): nine shifted gemm_nt launches
+  for (int tap = 0; tap < 9; ++tap) {
+    g.X = dy; g.x_sr = dy_bs; g.ldx = HW; g.M1 = Cout;
+    g.Y = x; g.y_sr = x_bs; g.ldy = HW; g.M2 = Cin;
+    g.G = dw + tap; g.g_si = (long)Cin * 9; g.g_sj = 9;
+    g.shift_dh = tap / 3 - 1; g.shift_dw = tap % 3 - 1;
+    const int st = launch_nt(p, ws_floats, 0, 0L, (hipStream_t)stream);
+    if (st) return st;
+  }
+  return PIR_OK;
 }

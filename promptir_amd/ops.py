@@ -283,11 +283,11 @@ def conv3x3_wgrad(dy: torch.Tensor, x: torch.Tensor, like: torch.Tensor, out: Op
     dy, x = _planes(dy), _planes(x)
     b, cout, h, wd = dy.shape
     cin = x.shape[1]
-    hw = h * wd
     dw = _grad_out(like, out)
-    for tap in range(9):
-        gemm_nt(dy, 0, (0, 0, _bs(dy)), hw, x, 0, (0, 0, _bs(x)), hw, dw, tap, (0, cin * 9, 9),
-                cout, cin, hw, 1, 1, b, shift=(tap // 3 - 1, tap % 3 - 1, h, wd))
+    nws = lib.pir_conv3x3_wgrad_ws_floats(cout, cin, h, wd, b)
+    ws = workspace(nws, x.device)
+    check(lib.pir_conv3x3_wgrad(dy.data_ptr(), _bs(dy), x.data_ptr(), _bs(x), dw.data_ptr(), b, cout, cin, h, wd,
+                                ws.data_ptr(), ws.numel(), 0, _stream()), "pir_conv3x3_wgrad")
     return dw
 
 
