@@ -109,6 +109,15 @@ typedef struct {
 size_t pir_gemm_nt_ws_floats(int M1, int M2, int N, int O, int BR);
 int pir_gemm_nt(const pir_gemm_nt_t* args, pir_stream_t stream);
 
+/* bf16x3 matrix-core form of pir_conv3x3: A3 = pir_split_bf16x3_taps() of the weights, layout
+ * [3 parts][9 taps][a3_kp/16][M][16] bf16 with W(tap, m, k) = W[(flip ? 8-tap : tap)*st + m*sm + k*sk].
+ * Forward: st=1, sm=K*9, sk=9, flip=0 on w[M][K][3][3]; input gradient: st=1, sm=9, sk=M*9, flip=1 with the
+ * roles of M and K swapped.  Same results as pir_conv3x3 to fp32 rounding (the six-term product drops <= 2^-27). */
+int pir_split_bf16x3_taps(const float* W, int M, int K, long st, long sm, long sk, int flip, void* out,
+                          pir_stream_t stream);   /* out holds 9 * pir_split_bf16x3_bytes(M, K) bytes */
+int pir_conv3x3_x3(const void* A3, int a3_kp, const float* X, long x_bs, float* Y, long y_bs,
+                   const float* R, long r_bs, int B, int M, int K, int H, int W, pir_stream_t stream);
+
 /* Weight gradient of the dense 3x3 convolutions (pir_conv3x3) in one call:
  *   dw[co][ci][dh+1][dw+1] (+)= sum_{b,h,w} dy[b][co][h][w] * x[b][ci][h+dh][w+dw]   (zero padding)
  * = what autograd derives for OverlapPatchEmbed.proj, Down/Upsample.body[0], PromptGenBlock.conv3x3 and

@@ -58,6 +58,8 @@ SIGNATURES = {
     "pir_conv3x3": (I, [P, L, L, L, I, P, L, P, L, P, L, I, I, I, I, I, S]),
     "pir_gemm_nt_ws_floats": (Z, [I, I, I, I, I]),
     "pir_gemm_nt": (I, [C.POINTER(GemmNT), S]),
+    "pir_split_bf16x3_taps": (I, [P, I, I, L, L, L, I, P, S]),
+    "pir_conv3x3_x3": (I, [P, I, P, L, P, L, P, L, I, I, I, I, I, S]),
     "pir_conv3x3_wgrad_ws_floats": (Z, [I, I, I, I, I]),
     "pir_conv3x3_wgrad": (I, [P, L, P, L, P, I, I, I, I, I, P, Z, I, S]),
     "pir_layernorm_fwd": (I, [P, L, P, P, P, L, P, P, I, I, I, S]),

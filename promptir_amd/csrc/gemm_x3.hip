@@ -36,9 +36,13 @@ __device__ __forceinline__ Frag3 split8(const float (&v)[8], bool ok) {
   return f;
 }
 
+// dense 3x3 convolution as 9 x ceil(K/16) stages: stage it = (tap, k-step); the tap shifts the activation columns
+struct X3Conv { int H, W, ksteps; unsigned magic_ks, magic_w; };
+
 // A_PRE: A comes pre-split (pir_split_bf16x3): a fragment is three 16-byte loads, no conversion work.
-template <int TM, int TN, int WM, int WN, bool A_MFAST, bool A_PRE>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_nn_x3_kernel(pir_gemm_nn_t g) {
+// CONV (needs A_PRE, weights from pir_split_bf16x3_taps): the k loop also runs over the nine taps.
+template <int TM, int TN, int WM, int WN, bool A_MFAST, bool A_PRE, bool CONV = false>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, T = WM * WN * 64;
   constexpr int AKS = BM + 4;              // 16-byte units between the two k-groups of A (+4: bank shift)
   constexpr int AU = 2 * AKS, BU = 2 * BN; // units per part
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_x3_kernel(pir_gemm_nn_t g
   constexpr int AF = 2 * BM, NA = (AF + T - 1) / T;   // 8-deep k fragments per stage
   constexpr int BF = 2 * BN, NB = (BF + T - 1) / T;
   struct Stage { float a[A_PRE ? 1 : NA][8]; bf16x8 a3[A_PRE ? NA : 1][3]; float b[NB][8]; };
-  const int iters = (g.K + XK - 1) / XK;
+  const int iters = CONV ? 9 * cv.ksteps : (g.K + XK - 1) / XK;
 
   // fragment -> (row, k-group).  k-fast A (forward weights): the two k-groups of a row sit on adjacent lanes
   auto a_map = [&](int f, int& mm, int& kg) { if (A_MFAST) { mm = f % BM; kg = f / BM; } else { kg = f & 1; mm = f >> 1; } };
@@ -67,14 +71,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_x3_kernel(pir_gemm_nn_t g
   // through the hardware range check, so the k tail needs no masks; per-lane offsets are computed once and
   // each load adds a scalar row offset (no vector address arithmetic inside the k loop).
   const __amdgpu_buffer_rsrc_t xrs = pir_make_rsrc(X, (unsigned)((((long)g.K - 1) * g.ldx + g.N) * 4));
-  const __amdgpu_buffer_rsrc_t ars = pir_make_rsrc(g.A3, A_PRE ? (unsigned)(6L * g.M * g.a3_kp) : 0u);
+  const __amdgpu_buffer_rsrc_t ars = pir_make_rsrc(g.A3, A_PRE ? (unsigned)((CONV ? 54L : 6L) * g.M * g.a3_kp) : 0u);
   static_assert(BF % T == 0, "B fragments must tile the workgroup");
-  int b_voff[NB], b_kg[NB], a_voff[NA];
+  int b_voff[NB], b_kg[NB], a_voff[NA], b_taps[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int f = tid + i * T;
-    b_voff[i] = (n0 + f % BN) * 4;
+    const int n = n0 + f % BN;
+    b_voff[i] = n * 4;
     b_kg[i] = __builtin_amdgcn_readfirstlane(f / BN);   // BN is a multiple of 64: uniform per wave
+    b_taps[i] = 0;
+    if (CONV) {  // bit t set: tap t of this pixel column lies inside the image
+      const int hh = pir_fastdiv(n, cv.magic_w), ww = n - hh * cv.W;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int hs = hh + t / 3 - 1, ws = ww + t % 3 - 1;
+        if (n < g.N && hs >= 0 && hs < cv.H && ws >= 0 && ws < cv.W) b_taps[i] |= 1 << t;
+      }
+    }
   }
 #pragma unroll
   for (int i = 0; i < NA; ++i) {   // pre-split A: lanes (2r, 2r+1) = the two k-groups of row r -> 1 KB contiguous per wave
@@ -84,11 +98,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_x3_kernel(pir_gemm_nn_t g
     const int m = m0 + mm, mc = m < g.M ? m : g.M - 1;
     a_voff[i] = (mc * 16 + 8 * kg) * 2;
   }
-  const int a3_part_bytes = g.M * g.a3_kp * 2, a3_step_bytes = g.M * 32, ldx4 = (int)g.ldx * 4;
+  const int a3_part_bytes = (CONV ? 9 : 1) * g.M * g.a3_kp * 2, a3_step_bytes = g.M * 32, ldx4 = (int)g.ldx * 4;
 
   auto load = [&](int it_raw, Stage& st) {
     const int it = it_raw < iters ? it_raw : iters - 1;
-    const int k0 = it * XK, klast = g.K - 1 - k0;
+    int tap = 0, ks = it;
+    if (CONV) { tap = pir_fastdiv(it, cv.magic_ks); ks = it - tap * cv.ksteps; }
+    const int k0 = ks * XK, klast = g.K - 1 - k0;
+    const int tap_shift = CONV ? ((tap / 3 - 1) * cv.W + tap % 3 - 1) * 4 : 0;
     const float* __restrict__ At = A + (long)k0 * g.a_sk;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -111,10 +128,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_x3_kernel(pir_gemm_nn_t g
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
+      // a column whose tap falls outside the image gets an out-of-range offset: the loads return 0
+      const int voff = CONV ? (((b_taps[i] >> tap) & 1) ? b_voff[i] + tap_shift : 0x7ffffff0) : b_voff[i];
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         st.b[i][j] = __builtin_bit_cast(
-            float, __builtin_amdgcn_raw_buffer_load_b32(xrs, b_voff[i], (k0 + 8 * b_kg[i] + j) * ldx4, 0));
+            float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff, (k0 + 8 * b_kg[i] + j) * ldx4, 0));
     }
   };
 
@@ -446,13 +465,15 @@ int launch_pp(const pir_gemm_nn_t& g, hipStream_t s) {
 }
 
 template <int TM, int TN, int WM, int WN>
-int launch_cfg(const pir_gemm_nn_t& g, hipStream_t s) {
+int launch_cfg(const pir_gemm_nn_t& g, hipStream_t s, const X3Conv* conv = nullptr) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const long tiles = pir_cdiv(g.M, BM) * pir_cdiv(g.N, BN);
   dim3 grid((unsigned)tiles, (unsigned)(g.O1 * g.O2)), block(WM * WN * 64);
-  if (g.A3) hipLaunchKernelGGL((gemm_nn_x3_kernel<TM, TN, WM, WN, true, true>), grid, block, 0, s, g);
-  else if (g.a_sm == 1) hipLaunchKernelGGL((gemm_nn_x3_kernel<TM, TN, WM, WN, true, false>), grid, block, 0, s, g);
-  else hipLaunchKernelGGL((gemm_nn_x3_kernel<TM, TN, WM, WN, false, false>), grid, block, 0, s, g);
+  X3Conv cv = {0, 0, 0, 0u, 0u};
+  if (conv) hipLaunchKernelGGL((gemm_nn_x3_kernel<TM, TN, WM, WN, true, true, true>), grid, block, 0, s, g, *conv);
+  else if (g.A3) hipLaunchKernelGGL((gemm_nn_x3_kernel<TM, TN, WM, WN, true, true>), grid, block, 0, s, g, cv);
+  else if (g.a_sm == 1) hipLaunchKernelGGL((gemm_nn_x3_kernel<TM, TN, WM, WN, true, false>), grid, block, 0, s, g, cv);
+  else hipLaunchKernelGGL((gemm_nn_x3_kernel<TM, TN, WM, WN, false, false>), grid, block, 0, s, g, cv);
   return pir_launch_status();
 }
 
@@ -474,7 +495,63 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
   }
 }
 
+// nine taps: out[part][tap][k/16][m][k%16] of W(tap, m, k) = W[(flip ? 8 - tap : tap) * st + m * sm + k * sk]
+__global__ __launch_bounds__(256) void split_bf16x3_taps_kernel(const float* __restrict__ W, int M, int K, long st, long sm,
+                                                                long sk, int flip, __bf16* __restrict__ out, int kp) {
+  const long per_tap = (long)M * kp, total = 9 * per_tap;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(e / per_tap);
+    const long r = e - tap * per_tap;
+    const int m = (int)(r / kp), k = (int)(r % kp);
+    const float x = k < K ? W[(flip ? 8 - tap : tap) * st + m * sm + k * sk] : 0.f;
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;
+    const __bf16 mid = (__bf16)r1;
+    const float r2 = r1 - (float)mid;
+    const long d = tap * per_tap + ((long)(k >> 4) * M + m) * 16 + (k & 15);
+    out[d] = h; out[total + d] = mid; out[2 * total + d] = (__bf16)r2;
+  }
+}
+
 }  // namespace
+
+extern "C" int pir_split_bf16x3_taps(const float* W, int M, int K, long st, long sm, long sk, int flip, void* out,
+                                     pir_stream_t stream) {
+  PIR_CHECK_ARG(W && out && M > 0 && K > 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  const int kp = (int)(pir_cdiv(K, 16) * 16);
+  const long total = 9L * M * kp;
+  const int blocks = (int)(pir_cdiv(total, 256) < 2048 ? pir_cdiv(total, 256) : 2048);
+  hipLaunchKernelGGL(split_bf16x3_taps_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, M, K, st, sm, sk, flip,
+                     reinterpret_cast<__bf16*>(out), kp);
+  return pir_launch_status();
+}
+
+extern "C" int pir_conv3x3_x3(const void* A3, int a3_kp, const float* X, long x_bs, float* Y, long y_bs, const float* R,
+                              long r_bs, int B, int M, int K, int H, int W, pir_stream_t stream) {
+  PIR_CHECK_ARG(A3 && X && Y && B > 0 && M > 0 && K > 0 && H > 0 && W > 0 && B <= 65535);
+  PIR_CHECK_ARG(a3_kp == (int)(pir_cdiv(K, 16) * 16));
+  PIR_CHECK_ARG((long)(M > K ? M : K) * H * W < (1L << 28) && 54L * M * a3_kp < (1L << 31));
+  pir_gemm_nn_t g;
+  g.A = nullptr; g.a_s1 = g.a_s2 = 0; g.a_sm = 0; g.a_sk = 0;
+  g.X = X; g.x_s1 = x_bs; g.x_s2 = 0; g.ldx = (long)H * W;
+  g.Y = Y; g.y_s1 = y_bs; g.y_s2 = 0; g.ldy = (long)H * W;
+  g.R = R; g.r_s1 = r_bs; g.r_s2 = 0; g.ldr = (long)H * W;
+  g.rowscale = nullptr; g.rs_s1 = g.rs_s2 = 0;
+  g.M = M; g.K = K; g.N = H * W; g.O1 = B; g.O2 = 1;
+  g.A3 = A3; g.a3_kp = a3_kp;
+  X3Conv cv;
+  cv.H = H; cv.W = W; cv.ksteps = a3_kp / 16;
+  cv.magic_ks = pir_magic((unsigned)cv.ksteps); cv.magic_w = pir_magic((unsigned)W);
+  hipStream_t s = (hipStream_t)stream;
+  // tile choice as for gemm_nn (rows = output channels, often few)
+  if (M <= 32) return launch_cfg<1, 2, 1, 4>(g, s, &cv);
+  if (M <= 64) return launch_cfg<2, 2, 1, 4>(g, s, &cv);
+  const long pad96 = pir_cdiv(M, 96) * 96, pad128 = pir_cdiv(M, 128) * 128;
+  const long blocks128 = pir_cdiv(M, 128) * pir_cdiv(g.N, 128) * B;
+  if (pad96 <= pad128 && g.N >= 256) return launch_cfg<3, 2, 1, 4>(g, s, &cv);
+  if (blocks128 < 2L * PIR_NUM_CU && pir_cdiv(M, 64) * 64 <= pad128) return launch_cfg<1, 2, 2, 2>(g, s, &cv);
+  return launch_cfg<2, 2, 2, 2>(g, s, &cv);
+}
 
 extern "C" size_t pir_split_bf16x3_bytes(int M, int K) {
   if (M <= 0 || K <= 0) return 0;

@@ -51,6 +51,9 @@ class _TimedLib:
         if name == "pir_conv3x3":
             b, m, k, h, w = args[11:16]
             return 2.0 * 9 * m * k * h * w * b
+        if name == "pir_conv3x3_x3":
+            b, m, k, h, w = args[8:13]
+            return 2.0 * 9 * m * k * h * w * b
         return 0.0
 
     def __getattr__(self, name):
@@ -189,9 +192,10 @@ def weights_changed() -> None:
     _WEIGHT_GEN[0] += 1
 
 
-def _split_weight(w: torch.Tensor, dgrad: bool):
+def _split_weight(w: torch.Tensor, dgrad: bool, taps: bool = False):
+    """bf16x3 pieces of a 1x1 (taps=False) or dense 3x3 (taps=True) weight in forward / input-gradient orientation."""
     cout, cin = w.shape[0], w.shape[1]
-    M, K, sm, sk = (cin, cout, 1, cin) if dgrad else (cout, cin, cin, 1)
+    M, K = (cin, cout) if dgrad else (cout, cin)
     kp = (K + 15) // 16 * 16
     ver = (w.data_ptr(), w._version, _WEIGHT_GEN[0])
     key = id(w)
@@ -200,13 +204,21 @@ def _split_weight(w: torch.Tensor, dgrad: bool):
         rec = (_weakref.ref(w, lambda _r, _k=key: _SPLIT.pop(_k, None)), {})
         _SPLIT[key] = rec
     slot = rec[1]
-    ent = slot.get(dgrad)
+    skey = (dgrad, taps)
+    ent = slot.get(skey)
     if ent is not None and ent[0] == ver:
         return ent[1], kp
-    buf = ent[1] if ent is not None and ent[1].device == w.device else \
-        torch.empty(3 * M * kp, dtype=torch.bfloat16, device=w.device)
-    check(lib.pir_split_bf16x3(w.data_ptr(), M, K, sm, sk, buf.data_ptr(), _stream()), "pir_split_bf16x3")
-    slot[dgrad] = (ver, buf)
+    n = (27 if taps else 3) * M * kp
+    buf = ent[1] if ent is not None and ent[1].device == w.device and ent[1].numel() == n else \
+        torch.empty(n, dtype=torch.bfloat16, device=w.device)
+    if taps:   # w[cout][cin][3][3]; input gradient: transposed channels and 180-degree rotated taps
+        sm, sk = (9, cin * 9) if dgrad else (cin * 9, 9)
+        check(lib.pir_split_bf16x3_taps(w.data_ptr(), M, K, 1, sm, sk, int(dgrad), buf.data_ptr(), _stream()),
+              "pir_split_bf16x3_taps")
+    else:
+        sm, sk = (1, cin) if dgrad else (cin, 1)
+        check(lib.pir_split_bf16x3(w.data_ptr(), M, K, sm, sk, buf.data_ptr(), _stream()), "pir_split_bf16x3")
+    slot[skey] = (ver, buf)
     return buf, kp
 
 
@@ -262,9 +274,14 @@ def conv3x3_forward(x: torch.Tensor, w: torch.Tensor, residual: Optional[torch.T
     out = torch.empty((b, cout, h, wd), dtype=torch.float32, device=x.device)
     if residual is not None:
         residual = _planes(residual)
-    check(lib.pir_conv3x3(w.data_ptr(), 1, cin * 9, 9, 0, x.data_ptr(), _bs(x), out.data_ptr(), _bs(out),
-                          _p(residual), _bs(residual) if residual is not None else 0,
-                          b, cout, cin, h, wd, _stream()), "pir_conv3x3")
+    r_bs = _bs(residual) if residual is not None else 0
+    if USE_X3:
+        a3, kp = _split_weight(w, dgrad=False, taps=True)
+        check(lib.pir_conv3x3_x3(a3.data_ptr(), kp, x.data_ptr(), _bs(x), out.data_ptr(), _bs(out), _p(residual), r_bs,
+                                 b, cout, cin, h, wd, _stream()), "pir_conv3x3_x3")
+    else:
+        check(lib.pir_conv3x3(w.data_ptr(), 1, cin * 9, 9, 0, x.data_ptr(), _bs(x), out.data_ptr(), _bs(out),
+                              _p(residual), r_bs, b, cout, cin, h, wd, _stream()), "pir_conv3x3")
     return out
 
 
@@ -273,9 +290,14 @@ def conv3x3_dgrad(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     b, cout, h, wd = dy.shape
     cin = w.shape[1]
     out = torch.empty((b, cin, h, wd), dtype=torch.float32, device=dy.device)
-    # A(tap, m=cin, k=cout) = w[k][m][8-tap]
-    check(lib.pir_conv3x3(w.data_ptr(), 1, 9, cin * 9, 1, dy.data_ptr(), _bs(dy), out.data_ptr(), _bs(out),
-                          None, 0, b, cin, cout, h, wd, _stream()), "pir_conv3x3(dgrad)")
+    if USE_X3:
+        a3, kp = _split_weight(w, dgrad=True, taps=True)
+        check(lib.pir_conv3x3_x3(a3.data_ptr(), kp, dy.data_ptr(), _bs(dy), out.data_ptr(), _bs(out), None, 0,
+                                 b, cin, cout, h, wd, _stream()), "pir_conv3x3_x3(dgrad)")
+    else:
+        # A(tap, m=cin, k=cout) = w[k][m][8-tap]
+        check(lib.pir_conv3x3(w.data_ptr(), 1, 9, cin * 9, 1, dy.data_ptr(), _bs(dy), out.data_ptr(), _bs(out),
+                              None, 0, b, cin, cout, h, wd, _stream()), "pir_conv3x3(dgrad)")
     return out
 
 
