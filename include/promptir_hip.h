@@ -118,6 +118,16 @@ int pir_split_bf16x3_taps(const float* W, int M, int K, long st, long sm, long s
 int pir_conv3x3_x3(const void* A3, int a3_kp, const float* X, long x_bs, float* Y, long y_bs,
                    const float* R, long r_bs, int B, int M, int K, int H, int W, pir_stream_t stream);
 
+/* Every pre-split weight of a model refreshed by ONE launch (after an optimiser step): descs (device memory)
+ * lists the tensors, blocks (device memory, nblocks x {descriptor index, 4096-element chunk index}) the work.
+ * taps=0: as pir_split_bf16x3(W, M, K, sm, sk); taps=1: as pir_split_bf16x3_taps(W, M, K, st, sm, sk, flip). */
+typedef struct {
+  const float* W; void* out;
+  long st, sm, sk;
+  int M, K, taps, flip;
+} pir_split_desc_t;
+int pir_split_bf16x3_batch(const pir_split_desc_t* descs, const int* blocks, int nblocks, pir_stream_t stream);
+
 /* Weight gradient of the dense 3x3 convolutions (pir_conv3x3) in one call:
  *   dw[co][ci][dh+1][dw+1] (+)= sum_{b,h,w} dy[b][co][h][w] * x[b][ci][h+dh][w+dw]   (zero padding)
  * = what autograd derives for OverlapPatchEmbed.proj, Down/Upsample.body[0], PromptGenBlock.conv3x3 and

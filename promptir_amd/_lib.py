@@ -45,6 +45,11 @@ class GemmNT(C.Structure):
     ]
 
 
+class SplitDesc(C.Structure):
+    _fields_ = [("W", c_float_p), ("out", c_float_p), ("st", c_long), ("sm", c_long), ("sk", c_long),
+                ("M", c_int), ("K", c_int), ("taps", c_int), ("flip", c_int)]
+
+
 P, L, I, Z, F, S = c_float_p, c_long, c_int, c_size_t, c_float, stream_t
 
 # name -> (restype, argtypes); must list EVERY symbol of include/promptir_hip.h
@@ -58,6 +63,7 @@ SIGNATURES = {
     "pir_conv3x3": (I, [P, L, L, L, I, P, L, P, L, P, L, I, I, I, I, I, S]),
     "pir_gemm_nt_ws_floats": (Z, [I, I, I, I, I]),
     "pir_gemm_nt": (I, [C.POINTER(GemmNT), S]),
+    "pir_split_bf16x3_batch": (I, [P, P, I, S]),
     "pir_split_bf16x3_taps": (I, [P, I, I, L, L, L, I, P, S]),
     "pir_conv3x3_x3": (I, [P, I, P, L, P, L, P, L, I, I, I, I, I, S]),
     "pir_conv3x3_wgrad_ws_floats": (Z, [I, I, I, I, I]),

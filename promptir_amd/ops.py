@@ -192,33 +192,84 @@ def weights_changed() -> None:
     _WEIGHT_GEN[0] += 1
 
 
-def _split_weight(w: torch.Tensor, dgrad: bool, taps: bool = False):
-    """bf16x3 pieces of a 1x1 (taps=False) or dense 3x3 (taps=True) weight in forward / input-gradient orientation."""
+_BATCH = {"entries": [], "dirty": True, "descs": None, "blocks": None, "nblocks": 0, "ptrs": None}
+
+
+def _split_args(w: torch.Tensor, dgrad: bool, taps: bool):
     cout, cin = w.shape[0], w.shape[1]
     M, K = (cin, cout) if dgrad else (cout, cin)
+    if taps:   # w[cout][cin][3][3]; input gradient: transposed channels and 180-degree rotated taps
+        sm, sk = (9, cin * 9) if dgrad else (cin * 9, 9)
+    else:
+        sm, sk = (1, cin) if dgrad else (cin, 1)
+    return M, K, sm, sk
+
+
+def _refresh_split_batch() -> None:
+    """Re-split every registered weight with ONE launch (pir_split_bf16x3_batch) and mark all entries current."""
+    import numpy as np
+
+    ents = [e for e in _BATCH["entries"] if e["w"]() is not None]
+    ptrs = [(e["w"]().data_ptr(), e["buf"].data_ptr()) for e in ents]
+    if _BATCH["dirty"] or ptrs != _BATCH["ptrs"] or len(ents) != len(_BATCH["entries"]):
+        descs = (_lib.SplitDesc * len(ents))()
+        blocks = []
+        for i, e in enumerate(ents):
+            w = e["w"]()
+            M, K, sm, sk = _split_args(w, e["dgrad"], e["taps"])
+            d = descs[i]
+            d.W, d.out, d.st, d.sm, d.sk = w.data_ptr(), e["buf"].data_ptr(), 1, sm, sk
+            d.M, d.K, d.taps, d.flip = M, K, int(e["taps"]), int(e["taps"] and e["dgrad"])
+            total = (9 if e["taps"] else 1) * M * ((K + 15) // 16 * 16)
+            blocks += [(i, c) for c in range((total + 4095) // 4096)]
+        dev = ents[0]["buf"].device
+        raw = np.frombuffer(bytes(descs), dtype=np.uint8).copy()
+        _BATCH["descs"] = torch.from_numpy(raw).to(dev)
+        _BATCH["blocks"] = torch.tensor(blocks, dtype=torch.int32, device=dev).contiguous()
+        _BATCH["nblocks"], _BATCH["ptrs"], _BATCH["entries"], _BATCH["dirty"] = len(blocks), ptrs, ents, False
+    check(lib.pir_split_bf16x3_batch(_BATCH["descs"].data_ptr(), _BATCH["blocks"].data_ptr(), _BATCH["nblocks"], _stream()),
+          "pir_split_bf16x3_batch")
+    gen = _WEIGHT_GEN[0]
+    for e in ents:
+        w = e["w"]()
+        e["slot"][e["skey"]] = ((w.data_ptr(), w._version, gen), e["buf"])
+
+
+def _split_weight(w: torch.Tensor, dgrad: bool, taps: bool = False):
+    """bf16x3 pieces of a 1x1 (taps=False) or dense 3x3 (taps=True) weight in forward / input-gradient orientation.
+    The first request for a weight splits it alone and registers it; afterwards a stale entry (optimiser step)
+    refreshes ALL registered weights in one launch."""
+    M, K, sm, sk = _split_args(w, dgrad, taps)
     kp = (K + 15) // 16 * 16
     ver = (w.data_ptr(), w._version, _WEIGHT_GEN[0])
     key = id(w)
     rec = _SPLIT.get(key)
     if rec is None or rec[0]() is not w:
-        rec = (_weakref.ref(w, lambda _r, _k=key: _SPLIT.pop(_k, None)), {})
+        def _gone(_r, _k=key):
+            _SPLIT.pop(_k, None)
+            _BATCH["dirty"] = True
+        rec = (_weakref.ref(w, _gone), {})
         _SPLIT[key] = rec
     slot = rec[1]
     skey = (dgrad, taps)
     ent = slot.get(skey)
     if ent is not None and ent[0] == ver:
         return ent[1], kp
-    n = (27 if taps else 3) * M * kp
-    buf = ent[1] if ent is not None and ent[1].device == w.device and ent[1].numel() == n else \
-        torch.empty(n, dtype=torch.bfloat16, device=w.device)
-    if taps:   # w[cout][cin][3][3]; input gradient: transposed channels and 180-degree rotated taps
-        sm, sk = (9, cin * 9) if dgrad else (cin * 9, 9)
+    if ent is not None and ent[1].device == w.device:
+        _refresh_split_batch()
+        ent = slot.get(skey)
+        if ent is not None and ent[0] == ver:
+            return ent[1], kp
+    buf = torch.empty((27 if taps else 3) * M * kp, dtype=torch.bfloat16, device=w.device)
+    if taps:
         check(lib.pir_split_bf16x3_taps(w.data_ptr(), M, K, 1, sm, sk, int(dgrad), buf.data_ptr(), _stream()),
               "pir_split_bf16x3_taps")
     else:
-        sm, sk = (1, cin) if dgrad else (cin, 1)
         check(lib.pir_split_bf16x3(w.data_ptr(), M, K, sm, sk, buf.data_ptr(), _stream()), "pir_split_bf16x3")
     slot[skey] = (ver, buf)
+    _BATCH["entries"] = [e for e in _BATCH["entries"] if not (e["w"]() is w and e["skey"] == skey)]
+    _BATCH["entries"].append({"w": rec[0], "dgrad": dgrad, "taps": taps, "buf": buf, "slot": slot, "skey": skey})
+    _BATCH["dirty"] = True
     return buf, kp
 
 
