@@ -464,6 +464,199 @@ int launch_pp(const pir_gemm_nn_t& g, hipStream_t s) {
   return pir_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// "Convert at read" variant for pre-split weights: one persistent 8-wave workgroup per CU, tile 128 x 256,
+// every wave 64 x 64.  Global -> LDS copies are LDS-DMA (buffer_load ... lds, 16 bytes per lane): the fp32
+// activation rows and the bf16 weight pieces land in a 4-deep LDS ring without touching VGPRs, three stages
+// ahead.  There is no staging phase: each wave reads the raw fp32 values of ITS OWN B fragments of the NEXT
+// stage, splits them to bf16x3 in registers and reads its A fragments while the matrix pipe works on the
+// current stage (the conversion VALU ops are fillers in the shadow of the 32-cycle MFMAs).  One barrier per
+// k-step; the stage stream runs across tile boundaries as in the ping-pong kernel.
+constexpr int CR_BM = 128, CR_BN = 256, CR_RING = 4;
+constexpr int CR_A_BYTES = 3 * 2 * CR_BM * 16;     // [part][k-group][row] 16-byte units
+constexpr int CR_B_BYTES = XK * CR_BN * 4;         // [k][column] fp32
+constexpr int CR_STAGE = CR_A_BYTES + CR_B_BYTES;
+typedef __attribute__((address_space(3))) void* cr_lds_ptr;
+
+struct CRFrags { bf16x8 a[2][3], b[2][3]; };
+
+__global__ __launch_bounds__(512) void gemm_nn_cr_kernel(pir_gemm_nn_t g, int tiles_m, int tiles_n, int total) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[CR_RING * CR_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;
+  const int iters = (g.K + XK - 1) / XK;
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int my_tiles = (total - bid + G - 1) / G;
+  const int S = my_tiles * iters;
+  const int ldx4 = (int)g.ldx * 4;
+  const int a3_part_bytes = g.M * g.a3_kp * 2, a3_step_bytes = g.M * 32;
+  const __amdgpu_buffer_rsrc_t ars = pir_make_rsrc(g.A3, (unsigned)(6L * g.M * g.a3_kp));
+  const unsigned x_bytes = (unsigned)((((long)g.K - 1) * g.ldx + g.N) * 4);
+
+  // DMA roles of a wave, four 1 KB copies per stage: B rows 2*wid and 2*wid+1; A chunks q0 = wid and q1 = 8 + (wid & 3)
+  // (chunk q: part q/4, k-group (q>>1)&1, rows (q&1)*64 .. +63; waves 4-7 repeat chunks 8-11 so that every wave
+  // has exactly four loads per stage in flight and the vmcnt waits below are the same for all)
+  const int q0 = wid, q1 = 8 + (wid & 3);
+  auto chunk_lds = [&](int q) __attribute__((always_inline)) { return (((q >> 2) * 2 + ((q >> 1) & 1)) * CR_BM + (q & 1) * 64) * 16; };
+
+  auto tile_coords = [&](int ord, int& m0, int& n0, int& o) __attribute__((always_inline)) {
+    const int t = pir_xcd_remap(ord * G + bid, total);
+    m0 = (t % tiles_m) * CR_BM;
+    const int rest = t / tiles_m;
+    n0 = (rest % tiles_n) * CR_BN;
+    o = rest / tiles_n;
+  };
+
+  int l_ord = 0, l_k = 0, b_voff = 0, a_voff0 = 0, a_voff1 = 0;
+  __amdgpu_buffer_rsrc_t xrs = ars;
+  auto set_load_tile = [&](int ord) __attribute__((always_inline)) {
+    int m0, n0, o;
+    tile_coords(ord, m0, n0, o);
+    const int o1 = o / g.O2, o2 = o % g.O2;
+    xrs = pir_make_rsrc(g.X + o1 * g.x_s1 + o2 * g.x_s2, x_bytes);
+    b_voff = (n0 + lane * 4) * 4;
+    const int r0 = m0 + (q0 & 1) * 64 + lane, r1 = m0 + (q1 & 1) * 64 + lane;
+    a_voff0 = ((r0 < g.M ? r0 : g.M - 1) * 16 + 8 * ((q0 >> 1) & 1)) * 2;
+    a_voff1 = ((r1 < g.M ? r1 : g.M - 1) * 16 + 8 * ((q1 >> 1) & 1)) * 2;
+  };
+  set_load_tile(0);
+  // always four copies (past the last stage the cursor stays put and the ring slot it refills is never read)
+  auto issue = [&](int buf) __attribute__((always_inline)) {
+    unsigned char* st = smem + buf * CR_STAGE;
+    const int k0 = l_k * XK;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (cr_lds_ptr)(st + CR_A_BYTES + (2 * wid) * (CR_BN * 4)), 16, b_voff,
+                                             (k0 + 2 * wid) * ldx4, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (cr_lds_ptr)(st + CR_A_BYTES + (2 * wid + 1) * (CR_BN * 4)), 16, b_voff,
+                                             (k0 + 2 * wid + 1) * ldx4, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (cr_lds_ptr)(st + chunk_lds(q0)), 16, a_voff0,
+                                             (q0 >> 2) * a3_part_bytes + l_k * a3_step_bytes, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (cr_lds_ptr)(st + chunk_lds(q1)), 16, a_voff1,
+                                             (q1 >> 2) * a3_part_bytes + l_k * a3_step_bytes, 0, 0);
+    if (l_k + 1 < iters) {
+      ++l_k;
+    } else if (l_ord + 1 < my_tiles) {
+      l_k = 0;
+      set_load_tile(++l_ord);
+    }
+  };
+
+  const int fr_h = lane >> 5, fr_r = lane & 31;
+  auto read_a = [&](int buf, CRFrags& F) __attribute__((always_inline)) {
+    const unsigned char* ap = smem + buf * CR_STAGE + (fr_h * CR_BM + wm * 64 + fr_r) * 16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int part = 0; part < 3; ++part)
+        F.a[i][part] = *reinterpret_cast<const bf16x8*>(ap + (part * 2 * CR_BM + i * 32) * 16);
+  };
+  auto read_b_raw = [&](int buf, float (&raw)[2][8]) __attribute__((always_inline)) {
+    const float* bp = reinterpret_cast<const float*>(smem + buf * CR_STAGE + CR_A_BYTES) + 8 * fr_h * CR_BN + wn * 64 + fr_r;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) raw[j][t] = bp[t * CR_BN + j * 32];
+  };
+  auto convert_b = [&](const float (&raw)[2][8], CRFrags& F) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const Frag3 fr = split8(raw[j], true);
+      F.b[j][0] = fr.hi; F.b[j][1] = fr.mid; F.b[j][2] = fr.lo;
+    }
+  };
+
+  f32x16 acc[2][2];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  zero_acc();
+  int c_ord = 0, c_k = 0;
+  auto matrix = [&](const CRFrags& F) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16 c = acc[i][j];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][2], F.b[j][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][0], F.b[j][2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][1], F.b[j][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][1], F.b[j][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][0], F.b[j][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][0], F.b[j][0], c, 0, 0, 0);
+        acc[i][j] = c;
+      }
+  };
+  auto tile_end = [&]() __attribute__((always_inline)) {
+    if (++c_k == iters && c_ord < my_tiles) {
+      int m0, n0, o;
+      tile_coords(c_ord, m0, n0, o);
+      const int o1 = o / g.O2, o2 = o % g.O2;
+      float* __restrict__ Y = g.Y + o1 * g.y_s1 + o2 * g.y_s2;
+      pir_nn_epilogue<2, 2>(acc, g, Y, o1, o2, m0 + wm * 64, n0, 0, wn, lane);
+      zero_acc();
+      c_k = 0;
+      ++c_ord;
+    }
+  };
+
+  // prologue: stages 0..2 in flight, stage 0 landed and visible, its fragments in registers
+  issue(0); issue(1); issue(2);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __syncthreads();
+  CRFrags F0, F1;
+  {
+    float raw[2][8];
+    read_a(0, F0);
+    read_b_raw(0, raw);
+    convert_b(raw, F0);
+  }
+  int nbuf = 1, ibuf = 3;   // ring slots of stage s+1 (read in step s) and of stage s+3 (issued in step s)
+  auto step = [&](const CRFrags& cur, CRFrags& nxt) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // this wave's copies of stage s+1 have landed
+    __syncthreads();                                      // ... and everybody's; slot of stage s-1 is free
+    issue(ibuf);
+    float raw[2][8];
+    read_b_raw(nbuf, raw);
+    read_a(nbuf, nxt);
+    matrix(cur);
+    convert_b(raw, nxt);
+    // keep the conversion in THIS block (the compiler otherwise sinks it behind the tile-end branch, out of the
+    // MFMA shadow): an empty asm that "uses" the converted fragments
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int part = 0; part < 3; ++part) asm volatile("" : "+v"(nxt.b[j][part]));
+    // schedule of this block: all LDS reads up front, then every MFMA followed by a few conversion VALU ops
+    // (fillers in the 32-cycle shadow of the MFMA; left to itself the compiler clusters them behind the MFMAs)
+    __builtin_amdgcn_sched_group_barrier(0x100, 32, 0);
+#pragma unroll
+    for (int q = 0; q < 24; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+    }
+    tile_end();
+    nbuf = nbuf == CR_RING - 1 ? 0 : nbuf + 1;
+    ibuf = ibuf == CR_RING - 1 ? 0 : ibuf + 1;
+  };
+  for (int s = 0; s < S; s += 2) {
+    step(F0, F1);
+    step(F1, F0);
+  }
+}
+
+int launch_cr(const pir_gemm_nn_t& g, hipStream_t s) {
+  const int tiles_m = (int)pir_cdiv(g.M, CR_BM), tiles_n = (int)pir_cdiv(g.N, CR_BN);
+  const long total = (long)tiles_m * tiles_n * g.O1 * g.O2;
+  const int grid = total < PIR_NUM_CU ? (int)total : PIR_NUM_CU;
+  hipLaunchKernelGGL(gemm_nn_cr_kernel, dim3(grid), dim3(512), 0, s, g, tiles_m, tiles_n, (int)total);
+  return pir_launch_status();
+}
+
 template <int TM, int TN, int WM, int WN>
 int launch_cfg(const pir_gemm_nn_t& g, hipStream_t s, const X3Conv* conv = nullptr) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -615,6 +808,7 @@ int pir_nn_x3_launch(const pir_gemm_nn_t* a, int cfg, hipStream_t s) {
   const int M = g.M;
   const long batch = (long)g.O1 * g.O2;
   if (cfg == 5 && g.A3) return launch_pp(g, s);
+  if (cfg == 6 && g.A3) return launch_cr(g, s);
   if (cfg >= 0) {
     switch (cfg) {
       case 0: return launch_cfg<1, 2, 1, 4>(g, s);

@@ -22,7 +22,7 @@ for name, cin, cout, S in SHAPES:
     dy = r(B, cout, S, S)
     outs = {}
     line = f"{name:12s} M={cout:4d} K={cin:4d} N={S*S:5d}"
-    for knob in (-1, 5):
+    for knob in (-1, int(os.environ.get("CFG", "5"))):
         rawlib.pir_tune_set(0, knob)
         out = torch.empty(B, cout, S, S, device=DEV)
         ops.conv1x1_forward(x, w, res, out=out)
@@ -33,6 +33,6 @@ for name, cin, cout, S in SHAPES:
         t2 = timeit(lambda: ops.conv1x1_dgrad(dy, w, out=dx))
         line += f" | cfg {knob:2d}: fwd {t*1e6:7.1f} dgrad {t2*1e6:7.1f}"
     rawlib.pir_tune_set(0, -1)
-    e1 = (outs[-1][0] - outs[5][0]).abs().max().item()
-    e2 = (outs[-1][1] - outs[5][1]).abs().max().item()
+    e1 = (outs[-1][0] - outs[int(os.environ.get("CFG", "5"))][0]).abs().max().item()
+    e2 = (outs[-1][1] - outs[int(os.environ.get("CFG", "5"))][1]).abs().max().item()
     print(line + f" | maxdiff {e1:.2e} {e2:.2e}", flush=True)

@@ -12,7 +12,7 @@ from tools.kbench import r, timeit, DEV  # noqa: E402
 
 B = 32
 tag = os.environ.get("PIR_LIB", "default").split("/")[-1]
-rawlib.pir_tune_set(0, 5)
+rawlib.pir_tune_set(0, int(os.environ.get("CFG", "5")))
 line = f"{tag:14s}"
 for name, cin, cout, S in (("n3", 704, 3744, 16), ("L4", 384, 2042, 16), ("L3", 192, 1020, 32), ("L1'", 96, 510, 128)):
     x, w = r(B, cin, S, S), r(cout, cin, 1, 1)
