@@ -13,6 +13,9 @@
 // holds A[row r][k = 8h + j] and B[k = 8h + j][col r], j = 0..7  => one 16-byte LDS read per fragment from a
 // [k-group][row][8 x bf16] image.  The split happens when a stage is written to LDS.
 #include "gemm_common.h"
+#ifndef X3_FILL
+#define X3_FILL 0   // N > 0: place N conversion VALU ops behind each MFMA of the main loop (measured: no gain)
+#endif
 
 namespace {
 
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_x3_kernel(pir_gemm_nn_t g
     }
   };
 
-  auto stash = [&](int buf, int it, const Stage& st) {
+  auto stash_a = [&](int buf, int it, const Stage& st) {
     bf16x8* base = smem + buf * STAGE;
     const int klast = g.K - 1 - it * XK;
 #pragma unroll
@@ -159,6 +162,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_x3_kernel(pir_gemm_nn_t g
         }
       }
     }
+  };
+  auto stash_b = [&](int buf, const Stage& st) {
+    bf16x8* base = smem + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int f = tid + i * T;
@@ -167,6 +173,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_x3_kernel(pir_gemm_nn_t g
       const int u = AU + kg * BN + nn;
       base[u] = fr.hi; base[PART + u] = fr.mid; base[2 * PART + u] = fr.lo;
     }
+  };
+  auto stash = [&](int buf, int it, const Stage& st) {
+    stash_a(buf, it, st);
+    stash_b(buf, st);
+  };
+  // compute(cur) and the split of the next stage's activations share one basic block; ask the scheduler for
+  // LDS reads first, then a few conversion VALU ops in the shadow of every MFMA, LDS writes last (left alone it
+  // clusters the VALU work behind the MFMAs, where nothing hides it)
+  auto interleave = [&]() {
+    __builtin_amdgcn_sched_group_barrier(0x100, 3 * (TM + TN), 0);
+#pragma unroll
+    for (int q = 0; q < TM * TN * 6; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, X3_FILL, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x200, 3 * NB, 0);
   };
 
   f32x16 acc[TM][TN];
@@ -214,11 +236,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_x3_kernel(pir_gemm_nn_t g
   for (; it + 1 < iters; it += 2) {
     if (it + 2 < iters) load(it + 2, s0);
     compute(0);
-    stash(1, it + 1, s1);
+    stash_b(1, s1);
+    if (X3_FILL > 0) interleave();
+    stash_a(1, it + 1, s1);
     __syncthreads();
     if (it + 3 < iters) load(it + 3, s1);
     compute(1);
-    if (it + 2 < iters) stash(0, it + 2, s0);
+    stash_b(0, s0);   // harmless past the end (slot 0 is not read again)
+    if (X3_FILL > 0) interleave();
+    if (it + 2 < iters) stash_a(0, it + 2, s0);
     __syncthreads();
   }
   if (it < iters) compute(0);
