@@ -123,9 +123,18 @@ def main():
         # bf16x3: each fp32-class product costs 6 bf16 MFMA passes, so the ceiling for ALGORITHMIC flops is
         # bf16 peak / 6; `frac` is then the MFMA-pipe utilisation.  The fp32-MFMA figure is kept beside it.
         peak = PEAK_BF16_MFMA_TFLOPS / X3_PASSES if x3 else PEAK_F32_MFMA_TFLOPS
+        # HBM bytes per launch from the committed PMC profile of this build (rocprofv3 cannot run inside the timed
+        # process): FETCH_SIZE x 2 (gfx950 wide-read correction) + WRITE_SIZE, averaged over the family's launches
+        traffic, traffic_note = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_final_hbm_traffic.json")
+        if x3 and args.batch == 32 and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            traffic = round((2.0 * tj["fetch_kb_per_launch_raw"] + tj["write_kb_per_launch"]) * 1e3)
+            traffic_note = tj["source"] + "; " + tj["note"]
         roofline = {"kernel": ("gemm_nn_x3_kernel" if x3 else "gemm_nn_kernel") + " (all instantiations behind pir_gemm_nn)",
                     "bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": None,
+                    "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
+                    "traffic_note": traffic_note,
                     "peak_note": "algorithmic fp32-class flops; peak = 2500 TF/s dense bf16 / 6 MFMA passes per product"
                                  if x3 else "fp32 MFMA peak",
                     "vs_fp32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
