@@ -323,9 +323,14 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_nt_kernel(NTParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wk = wid % WK, wmn = wid / WK, wm = wmn / WN, wn = wmn % WN;
   const int tiles_i = (g.M1 + BM - 1) / BM;
-  const int i0 = (blockIdx.x % tiles_i) * BM, j0 = (blockIdx.x / tiles_i) * BN;
-  const int split = blockIdx.y;
-  const int o = blockIdx.z, o1 = o / g.O2, o2 = o % g.O2;
+  // XCD-aware order: the output tiles of one split (same pixel range => same operand rows) are neighbours in the
+  // logical order, so they run on one XCD and share its L2 instead of each XCD fetching the rows from HBM
+  const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int rr = pir_xcd_remap(lin, gridDim.x * gridDim.y * gridDim.z);
+  const int tile = rr % (int)gridDim.x, rest = rr / (int)gridDim.x;
+  const int i0 = (tile % tiles_i) * BM, j0 = (tile / tiles_i) * BN;
+  const int split = rest % (int)gridDim.y;
+  const int o = rest / (int)gridDim.y, o1 = o / g.O2, o2 = o % g.O2;
 
   const float* __restrict__ Xb = g.X + o1 * g.x_s1 + o2 * g.x_s2;
   const float* __restrict__ Yb = g.Y + o1 * g.y_s1 + o2 * g.y_s2;
@@ -498,9 +503,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_x3_kernel(NTParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
   const int tiles_i = (g.M1 + BM - 1) / BM;
-  const int i0 = (blockIdx.x % tiles_i) * BM, j0 = (blockIdx.x / tiles_i) * BN;
-  const int split = blockIdx.y;
-  const int o = blockIdx.z, o1 = o / g.O2, o2 = o % g.O2;
+  // XCD-aware order: the output tiles of one split (same pixel range => same operand rows) are neighbours in the
+  // logical order, so they run on one XCD and share its L2 instead of each XCD fetching the rows from HBM
+  const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int rr = pir_xcd_remap(lin, gridDim.x * gridDim.y * gridDim.z);
+  const int tile = rr % (int)gridDim.x, rest = rr / (int)gridDim.x;
+  const int i0 = (tile % tiles_i) * BM, j0 = (tile / tiles_i) * BN;
+  const int split = rest % (int)gridDim.y;
+  const int o = rest / (int)gridDim.y, o1 = o / g.O2, o2 = o % g.O2;
   const float* __restrict__ Xb = g.X + o1 * g.x_s1 + o2 * g.x_s2;
   const float* __restrict__ Yb = g.Y + o1 * g.y_s1 + o2 * g.y_s2;
 

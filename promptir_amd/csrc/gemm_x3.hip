@@ -13,6 +13,9 @@
 // holds A[row r][k = 8h + j] and B[k = 8h + j][col r], j = 0..7  => one 16-byte LDS read per fragment from a
 // [k-group][row][8 x bf16] image.  The split happens when a stage is written to LDS.
 #include "gemm_common.h"
+#ifndef PP_STAGE_PRIO
+#define PP_STAGE_PRIO 0   // wave priority of the ping-pong kernel's staging phase (experiment knob)
+#endif
 #ifndef X3_FILL
 #define X3_FILL 0   // N > 0: place N conversion VALU ops behind each MFMA of the main loop (measured: no gain)
 #endif
@@ -461,18 +464,22 @@ __global__ __launch_bounds__(512) void gemm_nn_pp_kernel(pir_gemm_nn_t g, int ti
     auto ping = [&](PPRegs& R) __attribute__((always_inline)) {
       matrix_phase(F);
       phase_barrier();
+      __builtin_amdgcn_s_setprio(PP_STAGE_PRIO);
       stash(sbuf, R);
       issue(R);
       read_frags(cbuf == 2 ? 0 : cbuf + 1, F);
+      __builtin_amdgcn_s_setprio(0);
       phase_barrier();
       advance();
     };
     for (int s = 0; s < S; s += 4) { ping(R2); ping(R3); ping(R0); ping(R1); }
   } else {
     auto pong = [&](PPRegs& R) __attribute__((always_inline)) {
+      __builtin_amdgcn_s_setprio(PP_STAGE_PRIO);
       stash(sbuf, R);
       issue(R);
       read_frags(cbuf, F);
+      __builtin_amdgcn_s_setprio(0);
       phase_barrier();
       matrix_phase(F);
       phase_barrier();
