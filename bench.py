@@ -93,6 +93,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    trainer.prepare(x, t)          # hipGraph capture of fwd+bwd for this batch shape (not a training step)
     for _ in range(args.warmup):
         trainer.train_step(x, t)
     sync()
@@ -156,6 +157,7 @@ def main():
                                    f"batch {args.batch}/GPU x 3x{args.patch}x{args.patch}, all-in-one sigma mix "
                                    f"(BASELINE config 3; config 5 per-GPU sharding for N>1)",
                        "global_batch": args.batch * world, "patch": args.patch, "parallelism": f"dp{world}",
+                       "execution": f"hipGraph={int(trainer.graph)}, half-batch streams={trainer.micro_streams}",
                        "params": 35592263, "final_loss": float(loss)},
             "per_gpu_value": round(patches / elapsed / world, 3),
             "roofline": roofline, "cpu_baseline": cpu,

@@ -235,6 +235,13 @@ def _refresh_split_batch() -> None:
         e["slot"][e["skey"]] = ((w.data_ptr(), w._version, gen), e["buf"])
 
 
+def refresh_split_weights() -> None:
+    """Re-split every registered weight now (one launch).  For callers that replay a captured graph: no Python
+    runs inside the replay, so the pieces must be current before it starts."""
+    if _BATCH["entries"]:
+        _refresh_split_batch()
+
+
 def _split_weight(w: torch.Tensor, dgrad: bool, taps: bool = False):
     """bf16x3 pieces of a 1x1 (taps=False) or dense 3x3 (taps=True) weight in forward / input-gradient orientation.
     The first request for a weight splits it alone and registers it; afterwards a stale entry (optimiser step)
@@ -675,6 +682,47 @@ class MdtaCoreFn(torch.autograd.Function):
         return dqkv, _ret(dtemp, ctx.sink), None
 
 
+USE_SIDE_STREAM = _os.environ.get("PIR_SIDE_STREAM", "1") != "0"
+_SIDE_STREAMS = {}
+
+
+class _SideWgrads:
+    """Weight-gradient GEMMs of one block backward on a second HIP stream: they only feed the optimiser, so they
+    can overlap the input-gradient chain (complementary kernels share the CUs).  The operands are recorded on the
+    side stream (the caching allocator must not recycle them early) and `join()` orders the side work before
+    anything that follows on the main stream."""
+
+    def __init__(self, device):
+        self.main = torch.cuda.current_stream(device)
+        self.side = None
+        if USE_SIDE_STREAM and lib.records is None:   # the instrumented (timed) step stays on one stream
+            key = (device.index, self.main.cuda_stream)   # one side stream per main stream (two-stream training)
+            self.side = _SIDE_STREAMS.get(key)
+            if self.side is None:
+                self.side = _SIDE_STREAMS[key] = torch.cuda.Stream(device)
+        self.used = False
+
+    def wgrad(self, dy, x, like, sink):
+        dw = _grad_out(like, sink)
+        if self.side is None:
+            return conv1x1_wgrad(dy, x, like, dw)
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.side.wait_event(ev)
+        dy.record_stream(self.side)
+        x.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            conv1x1_wgrad(dy, x, like, dw)
+        self.used = True
+        return dw
+
+    def join(self):
+        if self.used:
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            self.main.wait_event(ev)
+
+
 class TransformerBlockFn(torch.autograd.Function):
     """x -> x + attn(norm1(x)) -> (+ ffn(norm2(.))) (net/model.py:192-196) as ONE autograd node.
 
@@ -707,27 +755,31 @@ class TransformerBlockFn(torch.autograd.Function):
         (x, n1w, temperature, wqkv, wdw1, wproj, n2w, win, wdw2, wout,
          xn1, m1, r1, qkv0, qkv, attn, gram, sumsq, out, x1, xn2, m2, r2, h0, g) = ctx.saved_tensors
         s_n1w, s_n1b, s_t, s_qkv, s_dw1, s_proj, s_n2w, s_n2b, s_in, s_dw2, s_out = ctx.sinks
+        # The four 1x1 weight gradients feed nothing downstream in this backward: they run on a side stream
+        # beside the input-gradient chain (joined before returning).
+        side = _SideWgrads(dx2.device)
         # ---- GDFN branch
         dg = conv1x1_dgrad(dx2, wout)
-        d_wout = conv1x1_wgrad(dx2, g, wout, s_out)
+        d_wout = side.wgrad(dx2, g, wout, s_out)
         dh0, d_wdw2 = gdfn_dwconv_backward(h0, wdw2, dg, s_dw2)
         del dg
         dxn2 = conv1x1_dgrad(dh0, win)
-        d_win = conv1x1_wgrad(dh0, xn2, win, s_in)
+        d_win = side.wgrad(dh0, xn2, win, s_in)
         del dh0
         dx1, d_n2w, d_n2b = layernorm_backward(dxn2, x1, n2w, ctx.with_bias[1], m2, r2, s_n2w, s_n2b, dres=dx2)
         del dxn2
         # ---- MDTA branch
         dout = conv1x1_dgrad(dx1, wproj)
-        d_wproj = conv1x1_wgrad(dx1, out, wproj, s_proj)
+        d_wproj = side.wgrad(dx1, out, wproj, s_proj)
         dqkv, d_temp = mdta_core_backward(dout, qkv, temperature, ctx.heads, attn, gram, sumsq, s_t)
         del dout
         dqkv0, d_wdw1 = dwconv_backward(dqkv, qkv0, wdw1, s_dw1)
         del dqkv
         dxn1 = conv1x1_dgrad(dqkv0, wqkv)
-        d_wqkv = conv1x1_wgrad(dqkv0, xn1, wqkv, s_qkv)
+        d_wqkv = side.wgrad(dqkv0, xn1, wqkv, s_qkv)
         del dqkv0
         dx, d_n1w, d_n1b = layernorm_backward(dxn1, x, n1w, ctx.with_bias[0], m1, r1, s_n1w, s_n1b, dres=dx1)
+        side.join()
         return (dx, _ret(d_n1w, s_n1w), _ret(d_n1b, s_n1b) if ctx.with_bias[0] else None, _ret(d_temp, s_t),
                 _ret(d_wqkv, s_qkv), _ret(d_wdw1, s_dw1), _ret(d_wproj, s_proj),
                 _ret(d_n2w, s_n2w), _ret(d_n2b, s_n2b) if ctx.with_bias[1] else None,
@@ -847,6 +899,13 @@ class L1LossFn(torch.autograd.Function):
 
 def l1_loss(restored: torch.Tensor, clean: torch.Tensor) -> torch.Tensor:
     return L1LossFn.apply(restored, clean)
+
+
+def add_(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a += b on flat fp32 buffers (pir_add)."""
+    _require_gpu(a, b)
+    check(lib.pir_add(a.data_ptr(), b.data_ptr(), a.data_ptr(), a.numel(), _stream()), "pir_add")
+    return a
 
 
 def adamw_step(param, grad, exp_avg, exp_avg_sq, step, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,

@@ -107,7 +107,8 @@ def allreduce_mean_(flat_grad: torch.Tensor, world_size: int) -> float:
 class DataParallelTrainer:
     """One process per GPU; the batch is sharded, the model is replicated."""
 
-    def __init__(self, net: nn.Module, lr: float = 2e-4, loss_fn=None):
+    def __init__(self, net: nn.Module, lr: float = 2e-4, loss_fn=None, micro_streams: Optional[int] = None,
+                 graph: Optional[bool] = None):
         self.net = net
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
@@ -117,15 +118,104 @@ class DataParallelTrainer:
         if loss_fn is None:
             from .ops import l1_loss as loss_fn
         self.loss_fn = loss_fn
+        # Two half-batches on two HIP streams: the kernels of one half (say a bandwidth-bound stencil) run beside
+        # those of the other (an MFMA-bound GEMM) and fill each other's idle units.  Each half writes its weight
+        # gradients into its own flat buffer (the sinks are captured at forward time); the halves are summed once.
+        if micro_streams is None:
+            micro_streams = int(os.environ.get("PIR_MICRO_STREAMS", "2"))
+        if graph is None:
+            graph = os.environ.get("PIR_GRAPH", "1") != "0"
+        self.graph, self._graph, self._graph_shape = bool(graph) and self.opt.param.is_cuda, None, None
+        self.micro_streams = micro_streams if self.opt.param.is_cuda else 1
+        if self.micro_streams == 2:
+            from . import ops
+
+            ops.USE_SIDE_STREAM = False   # the two halves already overlap; side streams inside both do not mix with capture
+            dev = self.opt.param.device
+            self._streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+            self._grad_b = torch.zeros_like(self.opt.grad)
+            self._half_w = [torch.full((), 0.5, dtype=torch.float32, device=dev) for _ in range(2)]
+            self._sinks = [[], []]
+            for n, p in self.opt.named:
+                o = self.opt.offsets[n]
+                self._sinks[0].append((p, self.opt.grad[o:o + p.numel()].view_as(p)))
+                self._sinks[1].append((p, self._grad_b[o:o + p.numel()].view_as(p)))
+
+    def _use_sinks(self, which: int) -> None:
+        for p, view in self._sinks[which]:
+            p._grad_sink = view
+
+    def _fwd_bwd(self, degrad_patch: torch.Tensor, clean_patch: torch.Tensor, two_streams: bool = True) -> torch.Tensor:
+        """forward + L1 + backward; leaves the batch-mean gradient in opt.grad and returns the loss (device scalar)."""
+        b = degrad_patch.shape[0]
+        if not (two_streams and self.micro_streams == 2 and b >= 2):
+            loss = self.loss_fn(self.net(degrad_patch), clean_patch)
+            loss.backward()
+            return loss.detach()
+        from . import ops
+
+        h = b // 2
+        parts = [(degrad_patch[:h], clean_patch[:h], h / b), (degrad_patch[h:], clean_patch[h:], (b - h) / b)]
+        main = torch.cuda.current_stream(degrad_patch.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        losses = []
+        for i, (x, t, w) in enumerate(parts):
+            st = self._streams[i]
+            st.wait_event(ready)
+            self._use_sinks(i)                       # captured by the autograd nodes of this forward
+            with torch.cuda.stream(st):
+                losses.append((self.loss_fn(self.net(x), t), self._half_w[i] if w == 0.5 else
+                               torch.full((), w, dtype=torch.float32, device=x.device)))
+        for i, (loss, w) in enumerate(losses):
+            with torch.cuda.stream(self._streams[i]):
+                loss.backward(gradient=w)
+        for st in self._streams:
+            done = torch.cuda.Event()
+            done.record(st)
+            main.wait_event(done)
+        self._use_sinks(0)
+        ops.add_(self.opt.grad, self._grad_b)        # mean over the batch = sum of the weighted halves
+        return losses[0][0].detach() * losses[0][1] + losses[1][0].detach() * losses[1][1]
+
+    def _capture(self, degrad_patch: torch.Tensor, clean_patch: torch.Tensor) -> None:
+        """hipGraph of forward + loss + backward on static input buffers.  The optimiser, the
+        all-reduce and the weight re-split stay outside (their arguments change from step to step)."""
+        self._sx, self._st = degrad_patch.clone(), clean_patch.clone()
+        side = torch.cuda.Stream(degrad_patch.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                # warm-up on a side stream: caches, workspaces, allocator pools
+            for _ in range(2):
+                self._fwd_bwd(self._sx, self._st)
+        torch.cuda.current_stream().wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._sloss = self._fwd_bwd(self._sx, self._st)
+        self._graph_shape = tuple(degrad_patch.shape)
+
+    def prepare(self, degrad_patch: torch.Tensor, clean_patch: torch.Tensor) -> None:
+        """Optional: build the graph for this batch shape now (otherwise the first train_step does it)."""
+        if self.graph and degrad_patch.is_cuda and (self._graph is None or self._graph_shape != tuple(degrad_patch.shape)):
+            self._capture(degrad_patch, clean_patch)
 
     def train_step(self, degrad_patch: torch.Tensor, clean_patch: torch.Tensor, lr: Optional[float] = None):
         """reference train.py:37-46 (+ optimizer.step of Lightning's loop)."""
-        restored = self.net(degrad_patch)
-        loss = self.loss_fn(restored, clean_patch)
-        loss.backward()
+        from . import ops
+
+        if self.graph and degrad_patch.is_cuda and ops.lib.records is None:
+            if self._graph is None or self._graph_shape != tuple(degrad_patch.shape):
+                self._capture(degrad_patch, clean_patch)
+            self._sx.copy_(degrad_patch)
+            self._st.copy_(clean_patch)
+            self._graph.replay()
+            loss = self._sloss.clone()
+        else:   # eager; the instrumented (per-kernel timed) step stays on one stream
+            loss = self._fwd_bwd(degrad_patch, clean_patch, two_streams=ops.lib.records is None)
         scale = allreduce_mean_(self.opt.grad, self.world)
         self.opt.step(lr=lr, grad_scale=scale)
-        return loss.detach()
+        if self.graph:
+            ops.refresh_split_weights()
+        return loss
 
     def checkpoint(self, epoch: int) -> dict:
         """Lightning-compatible dict: state_dict keys are `net.<PromptIR key>`."""
