@@ -748,8 +748,9 @@ NTPlan nt_plan(int M1, int M2, int N, int O, int BR, int bk = NT_BK) {
   const long tiles = pir_cdiv(M1, pl.bm) * pir_cdiv(M2, pl.bn) * O;
   pl.chunks_per_r = (int)pir_cdiv(N, bk);
   const long total = (long)BR * pl.chunks_per_r;
-  long want = pir_cdiv(3L * PIR_NUM_CU, tiles);          // ~3 blocks per CU overall
-  const long min_stages = 512 / bk;                       // at least 512 pixels per split
+  long want = 3L * PIR_NUM_CU / tiles;                   // all blocks resident at once (3 per CU): no second round
+  if (want < 1) want = 1;
+  const long min_stages = 128 / bk;                       // at least 128 pixels per split (sweeps at batch 8 and 32, tools/ktune.py)
   long max_by_work = total / min_stages > 0 ? total / min_stages : 1;
   long s = want < max_by_work ? want : max_by_work;
   if (g_nt_splits > 0) s = g_nt_splits < total ? g_nt_splits : total;

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from promptir_amd import ops  # noqa: E402
 from tools.kbench import LEVELS, r, timeit  # noqa: E402
 
-B = 32
+B = int(os.environ.get("B", "32"))
 lib = ops.lib
 
 
