@@ -48,3 +48,11 @@ def test_train_cli_checkpoint_and_resume(tmp_path):
     out2 = subprocess.run(cmd2, capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert out2.returncode == 0, out2.stderr[-2000:]
     assert "epoch 2" in out2.stdout
+
+
+def test_evaluate_cli_synthetic():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "evaluate.py"), "--synthetic", "2"], capture_output=True,
+                         text=True, cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("Denoise sigma=")]
+    assert len(lines) == 3 and all("psnr:" in l for l in lines)
