@@ -107,3 +107,19 @@ def test_shape_errors():
     bad = PromptIR(decoder=False, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1).to(dev)
     with pytest.raises(RuntimeError):  # the reference's decoder=False forward fails with a channel mismatch too
         bad(torch.zeros(1, 3, 64, 64, device=dev))
+
+
+def test_graphed_forward_matches_eager():
+    """hipGraph replay of the forward (promptir_amd/infer.py) returns exactly what the eager launches return."""
+    from promptir_amd import weights as W
+    from promptir_amd.infer import GraphedForward
+
+    dev = torch.device("cuda", 0)
+    net, _ = _net(dict(decoder=True, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1), 3, dev)
+    net.eval()
+    g = GraphedForward(net)
+    for seed in (1, 2):
+        x = torch.from_numpy(W.synthetic_pair(2, 64, 64, sigma=25, seed=seed)[0]).to(dev)
+        with torch.no_grad():
+            ref = net(x)
+        assert torch.equal(g(x), ref)
