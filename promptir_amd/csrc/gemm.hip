@@ -335,18 +335,20 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_nt_kernel(NTParams p) {
   const float* __restrict__ Xb = g.X + o1 * g.x_s1 + o2 * g.x_s2;
   const float* __restrict__ Yb = g.Y + o1 * g.y_s1 + o2 * g.y_s2;
 
-  const long total = (long)g.BR * p.chunks_per_r;
-  const long per = (total + p.splits - 1) / p.splits;
-  const long c_begin = split * per, c_end = (c_begin + per < total) ? c_begin + per : total;
+  const int total = g.BR * p.chunks_per_r;
+  const int per = (total + p.splits - 1) / p.splits;
+  const int c_begin = split * per, c_end = (c_begin + per < total) ? c_begin + per : total;
+  int l_r = c_begin / p.chunks_per_r, l_ch = c_begin - l_r * p.chunks_per_r;   // load cursor (no per-stage division)
 
   constexpr int CPR = NT_BK / VEC;                       // vector chunks per row of a stage
   constexpr int X_CH = CPR * BM, NX = (X_CH + T - 1) / T;
   constexpr int Y_CH = CPR * BN, NY = (Y_CH + T - 1) / T;
   float rx[NX][VEC], ry[NY][VEC];
 
-  auto load = [&](long c) {
-    const int r = (int)(c / p.chunks_per_r);
-    const int nb = (int)(c % p.chunks_per_r) * NT_BK;
+  auto load = [&]() {
+    const int r = l_r;
+    const int nb = l_ch * NT_BK;
+    if (++l_ch == p.chunks_per_r) { l_ch = 0; ++l_r; }
     const float* Xp = Xb + r * g.x_sr;
     const float* Yp = Yb + r * g.y_sr;
 #pragma unroll
@@ -415,12 +417,12 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_nt_kernel(NTParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   if (c_begin < c_end) {
-    load(c_begin);
+    load();
     stash(0);
     __syncthreads();
     int buf = 0;
-    for (long c = c_begin; c < c_end; ++c, buf ^= 1) {
-      if (c + 1 < c_end) load(c + 1);
+    for (int c = c_begin; c < c_end; ++c, buf ^= 1) {
+      if (c + 1 < c_end) load();
       constexpr int KW = NT_BK / WK;  // k-range of this wave inside the stage
       const float* Xs = smem + buf * STAGE + (wk * KW + (lane >> 5)) * XS + wm * TM * 32 + (lane & 31);
       const float* Ys = smem + buf * STAGE + NT_BK * XS + (wk * KW + (lane >> 5)) * YS + wn * TN * 32 + (lane & 31);
@@ -515,17 +517,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_x3_kernel(NTParams p) {
   const float* __restrict__ Yb = g.Y + o1 * g.y_s1 + o2 * g.y_s2;
 
   // the launcher sets chunks_per_r = ceil(N / 16) for this kernel
-  const long total = (long)g.BR * p.chunks_per_r;
-  const long per = (total + p.splits - 1) / p.splits;
-  const long c_begin = split * per, c_end = (c_begin + per < total) ? c_begin + per : total;
+  // 32-bit stage counters and an incremental (image, chunk) cursor: a 64-bit division per stage on the scalar
+  // unit costs more than the stage's MFMAs (the host checks BR * chunks_per_r < 2^31)
+  const int total = g.BR * p.chunks_per_r;
+  const int per = (total + p.splits - 1) / p.splits;
+  const int c_begin = split * per, c_end = (c_begin + per < total) ? c_begin + per : total;
+  int l_r = c_begin / p.chunks_per_r, l_ch = c_begin - l_r * p.chunks_per_r;   // load cursor
 
   constexpr int XF = 2 * BM, NX = (XF + T - 1) / T;    // fragments (8 pixels of one row) per stage
   constexpr int YF = 2 * BN, NY = (YF + T - 1) / T;
-  struct Stage { f32x4 x[NX][2]; f32x4 y[NY][2]; float ye[TAPS ? NY : 1]; };
+  struct Stage { f32x4 x[NX][2]; f32x4 y[NY][2]; float ye[TAPS ? NY : 1]; int nb; };
 
-  auto load = [&](long c, Stage& st) {
-    const int r = (int)(c / p.chunks_per_r);
-    const int nb = (int)(c % p.chunks_per_r) * X3_BK;
+  auto load = [&](Stage& st) {   // loads the stage under the cursor, then advances it
+    const int r = l_r;
+    const int nb = l_ch * X3_BK;
+    st.nb = nb;
+    if (++l_ch == p.chunks_per_r) { l_ch = 0; ++l_r; }
     const float* __restrict__ Xp = Xb + r * g.x_sr;
     const float* __restrict__ Yp = Yb + r * g.y_sr;
 #pragma unroll
@@ -570,9 +577,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_x3_kernel(NTParams p) {
       }
     }
   };
-  auto stash = [&](int buf, long c, const Stage& st) {
+  auto stash = [&](int buf, const Stage& st) {
     pir_bf16x8* base = smem + buf * STAGE;
-    const int nb = (int)(c % p.chunks_per_r) * X3_BK;
+    const int nb = st.nb;
 #pragma unroll
     for (int q = 0; q < NX; ++q) {
       const int f = tid + q * T;
@@ -657,19 +664,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_x3_kernel(NTParams p) {
 
   if (c_begin < c_end) {
     Stage s0, s1;
-    load(c_begin, s0);
-    if (c_begin + 1 < c_end) load(c_begin + 1, s1);
-    stash(0, c_begin, s0);
+    load(s0);
+    if (c_begin + 1 < c_end) load(s1);
+    stash(0, s0);
     __syncthreads();
-    long c = c_begin;
+    int c = c_begin;
     for (; c + 1 < c_end; c += 2) {
-      if (c + 2 < c_end) load(c + 2, s0);
+      if (c + 2 < c_end) load(s0);
       compute(0);
-      stash(1, c + 1, s1);
+      stash(1, s1);
       __syncthreads();
-      if (c + 3 < c_end) load(c + 3, s1);
+      if (c + 3 < c_end) load(s1);
       compute(1);
-      if (c + 2 < c_end) stash(0, c + 2, s0);
+      if (c + 2 < c_end) stash(0, s0);
       __syncthreads();
     }
     if (c < c_end) compute(0);
@@ -777,6 +784,7 @@ int launch_nt(NTParams& p, size_t ws_floats, int tap_sign, long g_st, hipStream_
                     al(g.Y, g.y_s1, g.y_s2, g.y_sr, g.ldy);
   const bool x3 = vec4 && (g_nt_x3 != 0 || tap_sign != 0);   // bf16x3 matrix-core path whenever rows are 16-byte aligned
   if (tap_sign != 0 && !x3) return PIR_EINVAL;
+  if ((long)g.BR * pir_cdiv(g.N, x3 ? X3_BK : NT_BK) >= 2147483647L) return PIR_EINVAL;   // 32-bit stage counters
   NTPlan pl = nt_plan(g.M1, g.M2, g.N, O, g.BR, x3 ? X3_BK : NT_BK);
   if ((size_t)pl.splits * O * g.M1 * g.M2 > ws_floats) return PIR_ENOMEM;
   p.splits = pl.splits;
