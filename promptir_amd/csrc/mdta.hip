@@ -9,10 +9,13 @@ namespace {
 constexpr float NORM_EPS = 1e-12f;  // F.normalize default eps
 
 // attn = softmax_j( gram[i][j] / (nq_i nk_j) * temperature ),  n* = max(sqrt(sumsq), eps)
-__global__ __launch_bounds__(256) void mdta_softmax_fwd_kernel(const float* __restrict__ gram,
-                                                               const float* __restrict__ sumsq,
-                                                               const float* __restrict__ temperature,
-                                                               float* __restrict__ attn, int heads, int c) {
+// 16 waves per map; a row (c <= 256 columns) is loaded ONCE into registers (the kernel is bound by the latency
+// of its dependent global loads, not by arithmetic), the column norms once per wave.
+__global__ __launch_bounds__(1024) void mdta_softmax_fwd_kernel(const float* __restrict__ gram,
+                                                                const float* __restrict__ sumsq,
+                                                                const float* __restrict__ temperature,
+                                                                float* __restrict__ attn, int heads, int c) {
+  constexpr int MAXJ = 4;
   const int bh = blockIdx.x, b = bh / heads, h = bh % heads, C = heads * c;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const float* G = gram + (long)bh * c * c;
@@ -20,35 +23,46 @@ __global__ __launch_bounds__(256) void mdta_softmax_fwd_kernel(const float* __re
   const float* sq = sumsq + (long)b * 2 * C + h * c;
   const float* sk = sq + C;
   const float t = temperature[h];
+  float inv_k[MAXJ];
+#pragma unroll
+  for (int u = 0; u < MAXJ; ++u) {
+    const int j = lane + 64 * u;
+    inv_k[u] = j < c ? 1.f / fmaxf(sqrtf(sk[j]), NORM_EPS) : 0.f;
+  }
   for (int i = wid; i < c; i += nw) {
     const float inv_q = 1.f / fmaxf(sqrtf(sq[i]), NORM_EPS);
+    float sv[MAXJ];
     float m = -INFINITY;
-    for (int j = lane; j < c; j += 64) {
-      const float s = G[i * c + j] * inv_q / fmaxf(sqrtf(sk[j]), NORM_EPS) * t;
-      m = fmaxf(m, s);
+#pragma unroll
+    for (int u = 0; u < MAXJ; ++u) {
+      const int j = lane + 64 * u;
+      sv[u] = j < c ? G[i * c + j] * inv_q * inv_k[u] * t : -INFINITY;
+      m = fmaxf(m, sv[u]);
     }
     m = pir_wave_max(m);
     float sum = 0.f;
-    for (int j = lane; j < c; j += 64) {
-      const float s = G[i * c + j] * inv_q / fmaxf(sqrtf(sk[j]), NORM_EPS) * t;
-      sum += expf(s - m);
+#pragma unroll
+    for (int u = 0; u < MAXJ; ++u) {
+      sv[u] = lane + 64 * u < c ? expf(sv[u] - m) : 0.f;
+      sum += sv[u];
     }
     sum = pir_wave_sum(sum);
     const float inv = 1.f / sum;
-    for (int j = lane; j < c; j += 64) {
-      const float s = G[i * c + j] * inv_q / fmaxf(sqrtf(sk[j]), NORM_EPS) * t;
-      A[i * c + j] = expf(s - m) * inv;
+#pragma unroll
+    for (int u = 0; u < MAXJ; ++u) {
+      const int j = lane + 64 * u;
+      if (j < c) A[i * c + j] = sv[u] * inv;
     }
   }
 }
 
 // Backward through softmax, temperature and both L2 normalisations (see include/promptir_hip.h).
-__global__ __launch_bounds__(256) void mdta_softmax_bwd_kernel(
+__global__ __launch_bounds__(1024) void mdta_softmax_bwd_kernel(
     const float* __restrict__ dattn, const float* __restrict__ attn, const float* __restrict__ gram,
     const float* __restrict__ sumsq, const float* __restrict__ temperature, float* __restrict__ dgram,
     float* __restrict__ alpha_q, float* __restrict__ alpha_k, float* __restrict__ dtemp_partial, int heads, int c) {
   constexpr int MAXJ = 4;  // c <= 256 columns per lane-strided pass
-  __shared__ float colred[4][256];
+  __shared__ float colred[16][256];
   __shared__ float red[16];
   const int bh = blockIdx.x, b = bh / heads, h = bh % heads, C = heads * c;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -71,11 +85,14 @@ __global__ __launch_bounds__(256) void mdta_softmax_bwd_kernel(
   for (int i = wid; i < c; i += nw) {
     const float nq = fmaxf(sqrtf(sq[i]), NORM_EPS);
     const float inv_q = 1.f / nq;
-    float dot = 0.f;
+    float dot = 0.f, av[MAXJ], dav[MAXJ], gv[MAXJ];   // the row's three operands, loaded once
 #pragma unroll
     for (int u = 0; u < MAXJ; ++u) {
       const int j = lane + 64 * u;
-      if (j < c) dot += dA[i * c + j] * A[i * c + j];
+      av[u] = j < c ? A[i * c + j] : 0.f;
+      dav[u] = j < c ? dA[i * c + j] : 0.f;
+      gv[u] = j < c ? G[i * c + j] : 0.f;
+      dot += dav[u] * av[u];
     }
     dot = pir_wave_sum(dot);
     float rowterm = 0.f;
@@ -83,8 +100,8 @@ __global__ __launch_bounds__(256) void mdta_softmax_bwd_kernel(
     for (int u = 0; u < MAXJ; ++u) {
       const int j = lane + 64 * u;
       if (j < c) {
-        const float dS = A[i * c + j] * (dA[i * c + j] - dot);
-        const float R = G[i * c + j] * inv_q * inv_k[u];
+        const float dS = av[u] * (dav[u] - dot);
+        const float R = gv[u] * inv_q * inv_k[u];
         dt_acc += dS * R;
         const float dR = t * dS;
         dG[i * c + j] = dR * inv_q * inv_k[u];
@@ -112,8 +129,8 @@ __global__ __launch_bounds__(256) void mdta_softmax_bwd_kernel(
 
 extern "C" int pir_mdta_softmax_fwd(const float* gram, const float* sumsq, const float* temperature,
                                     float* attn, int B, int heads, int c, pir_stream_t stream) {
-  PIR_CHECK_ARG(gram && sumsq && temperature && attn && B > 0 && heads > 0 && c > 0);
-  hipLaunchKernelGGL(mdta_softmax_fwd_kernel, dim3((unsigned)(B * heads)), dim3(256), 0, (hipStream_t)stream,
+  PIR_CHECK_ARG(gram && sumsq && temperature && attn && B > 0 && heads > 0 && c > 0 && c <= 256);
+  hipLaunchKernelGGL(mdta_softmax_fwd_kernel, dim3((unsigned)(B * heads)), dim3(1024), 0, (hipStream_t)stream,
                      gram, sumsq, temperature, attn, heads, c);
   return pir_launch_status();
 }
@@ -124,7 +141,7 @@ extern "C" int pir_mdta_softmax_bwd(const float* dattn, const float* attn, const
                                     int B, int heads, int c, pir_stream_t stream) {
   PIR_CHECK_ARG(dattn && attn && gram && sumsq && temperature && dgram && alpha_q && alpha_k && dtemp_partial);
   PIR_CHECK_ARG(B > 0 && heads > 0 && c > 0 && c <= 256);
-  hipLaunchKernelGGL(mdta_softmax_bwd_kernel, dim3((unsigned)(B * heads)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(mdta_softmax_bwd_kernel, dim3((unsigned)(B * heads)), dim3(1024), 0, (hipStream_t)stream,
                      dattn, attn, gram, sumsq, temperature, dgram, alpha_q, alpha_k, dtemp_partial, heads, c);
   return pir_launch_status();
 }

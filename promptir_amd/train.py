@@ -124,11 +124,11 @@ class DataParallelTrainer:
         # forward time); the parts are summed once.  Measured at batch 32 inside the hipGraph: 1 stream 131.9 ms,
         # 2: 125.0, 3: 122.9, 4: 122.3 (eager, two streams: 142.9 ms - the doubled launch count makes the CPU
         # the bottleneck, which is why this lives inside the graph).
-        if micro_streams is None:
-            micro_streams = int(os.environ.get("PIR_MICRO_STREAMS", "4"))
         if graph is None:
             graph = os.environ.get("PIR_GRAPH", "1") != "0"
         self.graph, self._graph, self._graph_shape = bool(graph) and self.opt.param.is_cuda, None, None
+        if micro_streams is None:   # part streams only pay inside the graph (eagerly the extra launches bind the CPU)
+            micro_streams = int(os.environ.get("PIR_MICRO_STREAMS", "4" if self.graph else "1"))
         self.micro_streams = max(1, micro_streams) if self.opt.param.is_cuda else 1
         if self.micro_streams > 1:
             from . import ops
