@@ -656,10 +656,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_x3_kernel(NTParams p) {
     for (int i = 0; i < TM; ++i) { ah[i] = xp[i * 32]; am[i] = xp[PART + i * 32]; al[i] = xp[2 * PART + i * 32]; }
 #pragma unroll
     for (int j = 0; j < TN; ++j) { bh[j] = yp[j * 32]; bm[j] = yp[PART + j * 32]; bl[j] = yp[2 * PART + j * 32]; }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = pir_mfma_x3(ah[i], am[i], al[i], bh[j], bm[j], bl[j], acc[i][j]);
+    // term-major: consecutive MFMAs hit different accumulators (same per-accumulator term order as pir_mfma_x3)
+#define PIR_X3_TERM(A_, B_)                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[i], B_[j], acc[i][j], 0, 0, 0);
+    PIR_X3_TERM(al, bh)
+    PIR_X3_TERM(ah, bl)
+    PIR_X3_TERM(am, bm)
+    PIR_X3_TERM(am, bh)
+    PIR_X3_TERM(ah, bm)
+    PIR_X3_TERM(ah, bh)
+#undef PIR_X3_TERM
   };
 
   if (c_begin < c_end) {

@@ -16,6 +16,9 @@
 #ifndef PP_STAGE_PRIO
 #define PP_STAGE_PRIO 0   // wave priority of the ping-pong kernel's staging phase (experiment knob)
 #endif
+#ifndef X3_VMEM_FILL
+#define X3_VMEM_FILL 1   // issue the prefetch loads one per MFMA inside the main loop
+#endif
 #ifndef X3_FILL
 #define X3_FILL 0   // N > 0: place N conversion VALU ops behind each MFMA of the main loop (measured: no gain)
 #endif
@@ -185,11 +188,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_x3_kernel(pir_gemm_nn_t g
   // LDS reads first, then a few conversion VALU ops in the shadow of every MFMA, LDS writes last (left alone it
   // clusters the VALU work behind the MFMAs, where nothing hides it)
   auto interleave = [&]() {
-    __builtin_amdgcn_sched_group_barrier(0x100, 3 * (TM + TN), 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 3 * (TM + TN), 0);     // fragment reads first
 #pragma unroll
     for (int q = 0; q < TM * TN * 6; ++q) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, X3_FILL, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // one MFMA ...
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);               // ... one global load in its shadow
+      if (X3_FILL > 0) __builtin_amdgcn_sched_group_barrier(0x002, X3_FILL, 0);
     }
     __builtin_amdgcn_sched_group_barrier(0x200, 3 * NB, 0);
   };
@@ -212,19 +216,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_x3_kernel(pir_gemm_nn_t g
     for (int i = 0; i < TM; ++i) { ah[i] = ap[i * 32]; am[i] = ap[PART + i * 32]; al[i] = ap[2 * PART + i * 32]; }
 #pragma unroll
     for (int j = 0; j < TN; ++j) { bh[j] = bp[j * 32]; bm[j] = bp[PART + j * 32]; bl[j] = bp[2 * PART + j * 32]; }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        f32x16 c = acc[i][j];
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], c, 0, 0, 0);
-        acc[i][j] = c;
-      }
+    // term-major order: consecutive MFMAs go to DIFFERENT accumulators (the per-accumulator order of the six
+    // terms, hence the result, is unchanged).  Left accumulator-major, the compiler emits six back-to-back
+    // dependent MFMAs per accumulator.
+#define PIR_X3_TERM(A_, B_)                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[i], B_[j], acc[i][j], 0, 0, 0);
+    PIR_X3_TERM(al, bh)
+    PIR_X3_TERM(ah, bl)
+    PIR_X3_TERM(am, bm)
+    PIR_X3_TERM(am, bh)
+    PIR_X3_TERM(ah, bm)
+    PIR_X3_TERM(ah, bh)
+#undef PIR_X3_TERM
   };
 
   // Two stages are loaded ahead into registers.  (Measured: making these loads unconditional so that the
@@ -236,17 +240,33 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_x3_kernel(pir_gemm_nn_t g
   stash(0, 0, s0);
   __syncthreads();
   int it = 0;
-  for (; it + 1 < iters; it += 2) {
+  // Main part: both prefetch loads are in range, so they sit in the same basic block as the MFMAs and the
+  // scheduler can be told to issue one vector-memory instruction behind each MFMA.  In-kernel cycle counters
+  // showed the load issue of a stage (19 instructions, ~40 cycles each in the wave's in-order stream) costing
+  // ~820 cycles per k-step in front of 1152 cycles of MFMAs.
+  for (; it + 3 < iters; it += 2) {
+    load(it + 2, s0);
+    compute(0);
+    stash_b(1, s1);
+    if (X3_VMEM_FILL) interleave();
+    stash_a(1, it + 1, s1);
+    __syncthreads();
+    load(it + 3, s1);
+    compute(1);
+    stash_b(0, s0);
+    if (X3_VMEM_FILL) interleave();
+    stash_a(0, it + 2, s0);
+    __syncthreads();
+  }
+  for (; it + 1 < iters; it += 2) {   // tail: at most three stages left, loads guarded
     if (it + 2 < iters) load(it + 2, s0);
     compute(0);
     stash_b(1, s1);
-    if (X3_FILL > 0) interleave();
     stash_a(1, it + 1, s1);
     __syncthreads();
     if (it + 3 < iters) load(it + 3, s1);
     compute(1);
     stash_b(0, s0);   // harmless past the end (slot 0 is not read again)
-    if (X3_FILL > 0) interleave();
     if (it + 2 < iters) stash_a(0, it + 2, s0);
     __syncthreads();
   }
