@@ -16,6 +16,9 @@
 #ifndef PP_STAGE_PRIO
 #define PP_STAGE_PRIO 0   // wave priority of the ping-pong kernel's staging phase (experiment knob)
 #endif
+#ifndef X3_MFMA_PRIO
+#define X3_MFMA_PRIO 0   // experiment knob: > 0 raises the wave priority around the MFMA cluster, < 0 raises it everywhere else
+#endif
 #ifndef X3_VMEM_FILL
 #define X3_VMEM_FILL 1   // issue the prefetch loads one per MFMA inside the main loop
 #endif
@@ -222,18 +225,23 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nn_x3_kernel(pir_gemm_nn_t g
 #define PIR_X3_TERM(A_, B_)                                                                   \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[i], B_[j], acc[i][j], 0, 0, 0);
+    if (X3_MFMA_PRIO > 0) __builtin_amdgcn_s_setprio(X3_MFMA_PRIO);
+    if (X3_MFMA_PRIO < 0) __builtin_amdgcn_s_setprio(0);
     PIR_X3_TERM(al, bh)
     PIR_X3_TERM(ah, bl)
     PIR_X3_TERM(am, bm)
     PIR_X3_TERM(am, bh)
     PIR_X3_TERM(ah, bm)
     PIR_X3_TERM(ah, bh)
+    if (X3_MFMA_PRIO > 0) __builtin_amdgcn_s_setprio(0);
+    if (X3_MFMA_PRIO < 0) __builtin_amdgcn_s_setprio(-X3_MFMA_PRIO);
 #undef PIR_X3_TERM
   };
 
   // Two stages are loaded ahead into registers.  (Measured: making these loads unconditional so that the
   // compiler can keep exact vmcnt counts is slower - the two extra stage loads per tile cost more than the
   // deeper prefetch gains, K is often only 3-6 stages.)
+  if (X3_MFMA_PRIO < 0) __builtin_amdgcn_s_setprio(-X3_MFMA_PRIO);
   Stage s0, s1;
   load(0, s0);
   if (iters > 1) load(1, s1);
