@@ -142,7 +142,7 @@ def main():
                     "launches_per_step": calls, "avg_launch_us": round(secs / max(calls, 1) * 1e6, 2),
                     "share_of_step_kernel_time": round(secs / total, 4) if total > 0 else None,
                     "families_ms": {k: round(v[1] * 1e3, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N=1 only
             cpu = cpu_baseline(sd, args.patch)
     sync()
 
