@@ -30,7 +30,7 @@ class GraphedForward:
                 self.net(sx)
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             sy = self.net(sx)
         return graph, sx, sy
 

@@ -197,7 +197,8 @@ class DataParallelTrainer:
                 self._fwd_bwd(self._sx, self._st)
         torch.cuda.current_stream().wait_stream(side)
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        # thread_local: the RCCL watchdog thread of a multi-GPU job may query its events while this thread captures
+        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
             self._sloss = self._fwd_bwd(self._sx, self._st)
         self._graph_shape = tuple(degrad_patch.shape)
 
@@ -242,7 +243,7 @@ def init_distributed() -> tuple:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("PIR_FORCE_PG") == "1") and not dist.is_initialized():   # PIR_FORCE_PG: 1-rank test
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = "nccl" if torch.cuda.is_available() else "gloo"
         if torch.cuda.is_available():
