@@ -40,32 +40,9 @@ __device__ __forceinline__ int pir_xcd_remap(int bid, int nwg) {
 static inline unsigned pir_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)(0x100000000ULL / d) + 1u; }
 __device__ __forceinline__ int pir_fastdiv(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }
 
-// Standard normal CDF Phi(v) = 0.5 * erfc(-v / sqrt(2)) for the erf form of GELU (F.gelu default, net/model.py:97).
-// Branch-free erfc: t = 1 / (1 + |x| / 2), erfc(|x|) = t * exp(-x^2 + P(t)) with the degree-9 Chebyshev fit of
-// Numerical Recipes (`erfcc`, fractional error < 1.2e-7 everywhere, i.e. fp32-class and relative in the tail) -
-// one reciprocal, one exponential and ten FMAs instead of libm erff's two-branch evaluation (measured: the fused
-// GDFN backward spends ~18 % of its time in erff).
-__device__ __forceinline__ float pir_norm_cdf(float v) {
-  const float x = v * 0.70710678118654752440f;
-  const float ax = fabsf(x);
-  const float t = __frcp_rn(1.f + 0.5f * ax);
-  float p = 0.17087277f;
-  p = fmaf(p, t, -0.82215223f);
-  p = fmaf(p, t, 1.48851587f);
-  p = fmaf(p, t, -1.13520398f);
-  p = fmaf(p, t, 0.27886807f);
-  p = fmaf(p, t, -0.18628806f);
-  p = fmaf(p, t, 0.09678418f);
-  p = fmaf(p, t, 0.37409196f);
-  p = fmaf(p, t, 1.00002368f);
-  p = fmaf(p, t, -1.26551223f);
-  const float half_erfc = 0.5f * t * __expf(fmaf(-ax, ax, p));   // 0.5 * erfc(|x|)
-  return x >= 0.f ? 1.f - half_erfc : half_erfc;
-}
-
-// gelu_erf(v) and its derivative from one CDF evaluation
+// gelu_erf(v) and its derivative from ONE erf evaluation (F.gelu default, net/model.py:97)
 __device__ __forceinline__ void pir_gelu_both(float v, float& g, float& dg) {
-  const float cdf = pir_norm_cdf(v);
+  const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752440f));
   const float pdf = 0.39894228040143267794f * __expf(-0.5f * v * v);
   g = v * cdf;
   dg = cdf + v * pdf;

@@ -30,9 +30,9 @@ struct DwArgs {
   unsigned magic_spr, magic_lpr;  // fast division by LPR+2 and LPR
 };
 
-__device__ __forceinline__ float gelu_erf(float v) { return v * pir_norm_cdf(v); }
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float v) {
-  const float cdf = pir_norm_cdf(v);
+  const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752440f));
   const float pdf = 0.39894228040143267794f * __expf(-0.5f * v * v);
   return cdf + v * pdf;
 }
