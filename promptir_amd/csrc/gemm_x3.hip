@@ -594,6 +594,8 @@ __global__ __launch_bounds__(512) void gemm_nn_cr_kernel(pir_gemm_nn_t g, int ti
                                              (q0 >> 2) * a3_part_bytes + l_k * a3_step_bytes, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (cr_lds_ptr)(st + chunk_lds(q1)), 16, a_voff1,
                                              (q1 >> 2) * a3_part_bytes + l_k * a3_step_bytes, 0, 0);
+  };
+  auto advance_cursor = [&]() __attribute__((always_inline)) {   // kept out of the MFMA block (it branches)
     if (l_k + 1 < iters) {
       ++l_k;
     } else if (l_ord + 1 < my_tiles) {
@@ -638,19 +640,17 @@ __global__ __launch_bounds__(512) void gemm_nn_cr_kernel(pir_gemm_nn_t g, int ti
   zero_acc();
   int c_ord = 0, c_k = 0;
   auto matrix = [&](const CRFrags& F) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        f32x16 c = acc[i][j];
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][2], F.b[j][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][0], F.b[j][2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][1], F.b[j][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][1], F.b[j][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][0], F.b[j][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][0], F.b[j][0], c, 0, 0, 0);
-        acc[i][j] = c;
-      }
+    // term-major: consecutive MFMAs go to different accumulators; F.a/F.b parts: 0 hi, 1 mid, 2 lo
+#define PIR_CR_TERM(PA, PB)                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][PA], F.b[j][PB], acc[i][j], 0, 0, 0);
+    PIR_CR_TERM(2, 0)
+    PIR_CR_TERM(0, 2)
+    PIR_CR_TERM(1, 1)
+    PIR_CR_TERM(1, 0)
+    PIR_CR_TERM(0, 1)
+    PIR_CR_TERM(0, 0)
+#undef PIR_CR_TERM
   };
   auto tile_end = [&]() __attribute__((always_inline)) {
     if (++c_k == iters && c_ord < my_tiles) {
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(512) void gemm_nn_cr_kernel(pir_gemm_nn_t g, int ti
   };
 
   // prologue: stages 0..2 in flight, stage 0 landed and visible, its fragments in registers
-  issue(0); issue(1); issue(2);
+  issue(0); advance_cursor(); issue(1); advance_cursor(); issue(2); advance_cursor();
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __syncthreads();
   CRFrags F0, F1;
@@ -680,6 +680,7 @@ __global__ __launch_bounds__(512) void gemm_nn_cr_kernel(pir_gemm_nn_t g, int ti
   auto step = [&](const CRFrags& cur, CRFrags& nxt) __attribute__((always_inline)) {
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // this wave's copies of stage s+1 have landed
     __syncthreads();                                      // ... and everybody's; slot of stage s-1 is free
+    // one basic block: copies of stage s+3, LDS reads of stage s+1, the MFMAs of stage s, the conversion of s+1
     issue(ibuf);
     float raw[2][8];
     read_b_raw(nbuf, raw);
@@ -692,15 +693,17 @@ __global__ __launch_bounds__(512) void gemm_nn_cr_kernel(pir_gemm_nn_t g, int ti
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int part = 0; part < 3; ++part) asm volatile("" : "+v"(nxt.b[j][part]));
-    // schedule of this block: all LDS reads up front, then every MFMA followed by a few conversion VALU ops
-    // (fillers in the 32-cycle shadow of the MFMA; left to itself the compiler clusters them behind the MFMAs)
+    // schedule: LDS reads first, then behind every MFMA one copy instruction (while there are any) and a few
+    // conversion VALU ops, all in the MFMA's 32-cycle shadow
     __builtin_amdgcn_sched_group_barrier(0x100, 32, 0);
 #pragma unroll
     for (int q = 0; q < 24; ++q) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
     }
     tile_end();
+    advance_cursor();
     nbuf = nbuf == CR_RING - 1 ? 0 : nbuf + 1;
     ibuf = ibuf == CR_RING - 1 ? 0 : ibuf + 1;
   };
