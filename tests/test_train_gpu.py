@@ -47,3 +47,30 @@ def test_two_train_steps_match_oracle_adamw():
     assert worst <= 1e-5, worst
     # gradients land in the flat buffer (sinks), p.grad aliases it
     assert net.output.weight.grad.data_ptr() == trainer.opt.grad.data_ptr() + 4 * trainer.opt.offsets["output.weight"]
+
+
+def test_graph_and_part_streams_match_the_eager_step():
+    """hipGraph replay with four part-batch streams == the eager single-stream step (same kernels, the batch sum of
+    the weight gradients is only re-associated across the parts)."""
+    from net.model import PromptIR
+    from promptir_amd.train import DataParallelTrainer
+
+    dev = torch.device("cuda:0")
+    ctor = dict(decoder=True, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1)
+    shapes = None
+    degraded, clean = W.synthetic_pair(8, 64, 64, sigma=[15, 25, 50, 25, 15, 50, 25, 15], seed=4)
+    x, t = torch.from_numpy(degraded).to(dev), torch.from_numpy(clean).to(dev)
+    results = []
+    for graph, streams in ((False, 1), (True, 2), (True, 1)):
+        net = PromptIR(**ctor)
+        shapes = shapes or {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        net.load_state_dict(util.params_for(shapes, 11))
+        net.to(dev)
+        trainer = DataParallelTrainer(net, lr=2e-4, micro_streams=streams, graph=graph)
+        losses = [float(trainer.train_step(x, t)) for _ in range(3)]
+        results.append((losses, trainer.opt.grad.clone(), trainer.opt.param.clone()))
+    ref_losses, ref_grad, ref_param = results[0]
+    for losses, grad, param in results[1:]:
+        assert np.allclose(losses, ref_losses, rtol=0, atol=2e-6), (losses, ref_losses)
+        assert float((grad - ref_grad).abs().max()) <= 2e-5 * float(ref_grad.abs().max())
+        assert float((param - ref_param).abs().max()) <= 2e-6
