@@ -494,8 +494,11 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_nt_kernel(NTParams p) {
 // are those of gemm_nt_kernel.  Needs 16-byte aligned rows and N % 4 == 0 (else the fp32 kernel runs).
 constexpr int X3_BK = 16;
 
+// waves_per_eu(3): three workgroups per CU (LDS allows it for every tile); the 128 x 128 tile would otherwise be
+// allocated 172 registers, four too many
 template <int TM, int TN, int WM, int WN, bool TAPS = false>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_x3_kernel(NTParams p) {
+__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(3)))
+void gemm_nt_x3_kernel(NTParams p) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, T = WM * WN * 64;
   constexpr int XKS = BM + 4, YKS = BN + 4;            // 16-byte units between the two k-groups
   constexpr int XU = 2 * XKS, YU = 2 * YKS, PART = XU + YU, STAGE = 3 * PART;
@@ -676,7 +679,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_x3_kernel(NTParams p) {
     stash(0, s0);
     __syncthreads();
     int c = c_begin;
-    for (; c + 1 < c_end; c += 2) {
+    // main part: both prefetch loads in range, so they are unconditional and the compiler keeps exact vmcnt counts
+    // (the loads of the stage after next stay in flight across the split: +8-12 % on every weight gradient;
+    // a third register stage would help further but triples the inlined loop body and spills)
+    for (; c + 3 < c_end; c += 2) {
+      load(s0);
+      compute(0);
+      stash(1, s1);
+      __syncthreads();
+      load(s1);
+      compute(1);
+      stash(0, s0);
+      __syncthreads();
+    }
+    for (; c + 1 < c_end; c += 2) {   // tail: loads guarded
       if (c + 2 < c_end) load(s0);
       compute(0);
       stash(1, s1);

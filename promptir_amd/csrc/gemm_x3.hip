@@ -53,8 +53,11 @@ struct X3Conv { int H, W, ksteps; unsigned magic_ks, magic_w; };
 
 // A_PRE: A comes pre-split (pir_split_bf16x3): a fragment is three 16-byte loads, no conversion work.
 // CONV (needs A_PRE, weights from pir_split_bf16x3_taps): the k loop also runs over the nine taps.
+// waves_per_eu: the 128-column tiles (<= 50 KB of LDS) fit three workgroups per CU once the compiler is told to
+// stay within 168 registers (it then also keeps the accumulators in VGPRs); the 256-column tiles run two.
 template <int TM, int TN, int WM, int WN, bool A_MFAST, bool A_PRE, bool CONV = false>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
+__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu((WM == 2 && WN == 2 && (A_PRE || TM * TN <= 2)) ? 3 : 2)))
+void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, T = WM * WN * 64;
   constexpr int AKS = BM + 4;              // 16-byte units between the two k-groups of A (+4: bank shift)
   constexpr int AU = 2 * AKS, BU = 2 * BN; // units per part
