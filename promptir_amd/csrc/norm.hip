@@ -140,9 +140,14 @@ __global__ __launch_bounds__(LN_PIX* WAVES) void ln_bwd_fused_kernel(
   __shared__ float red[2][WAVES][LN_PIX];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: channel
-  float accw[NREG], accb[NREG];                                      // tests and weight loads go scalar
+  // ONE_TILE (the 16-wave variant, 128-register cap): exactly one pixel tile per workgroup, so the per-channel
+  // dweight / dbias sums need no accumulators across tiles - each is reduced over the wave and written at once.
+  // (With accumulators and the residual staged, 5 * NREG live values per lane spilled 105 registers at NREG = 24.)
+  constexpr bool ONE_TILE = WAVES >= 16 && NREG >= 24;
+  float accw[ONE_TILE ? 1 : NREG], accb[ONE_TILE ? 1 : NREG];        // tests and weight loads go scalar
 #pragma unroll
-  for (int i = 0; i < NREG; ++i) { accw[i] = 0.f; accb[i] = 0.f; }
+  for (int i = 0; i < (ONE_TILE ? 1 : NREG); ++i) { accw[i] = 0.f; accb[i] = 0.f; }
+  float* row = ws + (long)blockIdx.x * 2 * C;
   const long total = (long)B * tiles;
   for (long t = blockIdx.x; t < total; t += gridDim.x) {
     const int b = (int)(t / tiles), p = (int)(t % tiles) * LN_PIX + lane;
@@ -157,7 +162,10 @@ __global__ __launch_bounds__(LN_PIX* WAVES) void ln_bwd_fused_kernel(
     const float mu = mean[(long)b * HW + pc];
     const float rs = rstd[(long)b * HW + pc];
     // phase A: issue every load of this tile (channel index clamped -> no branches, all in flight)
-    float g[NREG], xh[NREG], rr[NREG];
+    // The 16-wave variant runs under a 128-register cap (1024 threads): with the residual gradient staged too,
+    // 5 * NREG values per lane spill (105 registers at NREG = 24); it reads the residual in the final loop instead.
+    constexpr bool LATE_RES = WAVES >= 16 && NREG >= 24;
+    float g[NREG], xh[NREG], rr[LATE_RES ? 1 : NREG];
 #pragma unroll
     for (int i = 0; i < NREG; ++i) {
       const int c = wid + i * WAVES;             // wave-uniform
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(LN_PIX* WAVES) void ln_bwd_fused_kernel(
       const long step = (long)ic * WAVES * HW;
       g[i] = (dyb + step)[off0];
       xh[i] = (xb + step)[off0];
-      rr[i] = rb ? (rb + step)[off0] : 0.f;
+      if (!LATE_RES) rr[i] = rb ? (rb + step)[off0] : 0.f;
     }
     // phase B: arithmetic
     float s1 = 0.f, s2 = 0.f;
@@ -176,7 +184,10 @@ __global__ __launch_bounds__(LN_PIX* WAVES) void ln_bwd_fused_kernel(
       const float d = live ? g[i] : 0.f;
       const float xv = xh[i];
       const float xn = with_bias ? (xv - mu) * rs : xv * rs;   // what multiplies the weight in forward
-      if (ok) { accw[i] += d * xn; accb[i] += d; }
+      if (ONE_TILE) {
+        const float sw = pir_wave_sum(ok ? d * xn : 0.f), sb = pir_wave_sum(ok ? d : 0.f);
+        if (lane == 0 && live) { row[c] = sw; row[C + c] = sb; }
+      } else if (ok) { accw[i] += d * xn; accb[i] += d; }
       g[i] = d * weight[live ? c : 0];
       const float second = with_bias ? xn : xv;                // BiasFree: second sum is over g*x
       s1 += g[i];
@@ -199,17 +210,18 @@ __global__ __launch_bounds__(LN_PIX* WAVES) void ln_bwd_fused_kernel(
         float r;
         if (with_bias) r = rs * (g[i] - m1 - xh[i] * m2);
         else r = rs * g[i] - rs * rs * rs * xh[i] * m2;
-        r += rr[i];
+        r += LATE_RES ? (rb ? (rb + step)[off0] : 0.f) : rr[i];
         if (ok) (ob + step)[off0] = r;
       }
     }
   }
-  float* row = ws + (long)blockIdx.x * 2 * C;
+  if (!ONE_TILE) {
 #pragma unroll
-  for (int i = 0; i < NREG; ++i) {
-    const int c = wid + i * WAVES;
-    const float sw = pir_wave_sum(accw[i]), sb = pir_wave_sum(accb[i]);
-    if (lane == 0 && c < C) { row[c] = sw; row[C + c] = sb; }
+    for (int i = 0; i < NREG; ++i) {
+      const int c = wid + i * WAVES;
+      const float sw = pir_wave_sum(accw[i]), sb = pir_wave_sum(accb[i]);
+      if (lane == 0 && c < C) { row[c] = sw; row[C + c] = sb; }
+    }
   }
 }
 
@@ -295,8 +307,10 @@ static int ln_param_splits(int B, int C, int HW) {
   return (int)s;
 }
 
-static int ln_fused_blocks(int B, int HW) {
+static bool ln_use16(int B, int C, int HW);
+static int ln_fused_blocks(int B, int HW, bool one_tile = false) {
   const long total = (long)B * pir_cdiv(HW, LN_PIX);
+  if (one_tile) return (int)total;
   long g = pir_cdiv(total, 4);                      // >= 4 pixel tiles per workgroup amortise its tail
   if (g > 8L * PIR_NUM_CU) g = 8L * PIR_NUM_CU;
   if (total < 2L * PIR_NUM_CU) g = total;           // tiny tensors: one tile per workgroup
@@ -306,7 +320,7 @@ static bool ln_use16(int B, int C, int HW) { return (long)B * pir_cdiv(HW, LN_PI
 
 extern "C" size_t pir_layernorm_bwd_ws_floats(int B, int C, int HW) {
   if (B <= 0 || C <= 0 || HW <= 0) return 0;
-  const size_t a = (size_t)ln_param_splits(B, C, HW) * 2 * C, b = (size_t)ln_fused_blocks(B, HW) * 2 * C;
+  const size_t a = (size_t)ln_param_splits(B, C, HW) * 2 * C, b = (size_t)ln_fused_blocks(B, HW, ln_use16(B, C, HW) && C > 192) * 2 * C;
   return a > b ? a : b;
 }
 
@@ -322,7 +336,7 @@ extern "C" int pir_layernorm_bwd(const float* dy, long dy_bs, const float* x, lo
   int S;
   const bool w16 = ln_use16(B, C, HW);
   if (C <= 128 || w16) {
-    S = ln_fused_blocks(B, HW);
+    S = ln_fused_blocks(B, HW, w16 && C > 192);   // the NREG >= 24 variants take one tile per workgroup
     if ((size_t)S * 2 * C > ws_floats) return PIR_ENOMEM;
 #define PIR_LNB(NR, WV) hipLaunchKernelGGL((ln_bwd_fused_kernel<NR, WV>), dim3((unsigned)S), dim3(LN_PIX * WV), 0, s, \
       dy, dy_bs, x, x_bs, weight, with_bias, mean, rstd, dx, dx_bs, dres, dres_bs, ws, B, C, HW, tiles)
