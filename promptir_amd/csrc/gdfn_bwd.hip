@@ -183,40 +183,37 @@ __global__ __launch_bounds__(256) void gdfn_dw_bwd_kernel(GArgs a) {
   }
   __syncthreads();
 
-  // ---- phase 3: dx = dw^T(dt) and weight-gradient partial sums on the interior tile
+  // ---- phase 3: dx = dw^T(dt) and weight-gradient partial sums on the interior tile; the two planes of the pair
+  // one after the other (their register windows are then live one at a time: 36 instead of 72 registers)
   if (s < a.strips && col < a.W) {
     const int r0i = s * a.SR;
-    float da0[6], da1[6], da2[6], db0[6], db1[6], db2[6];   // dt windows (rows r, r+1, r+2 of DT)
-    float xa0[6], xa1[6], xa2[6], xb0[6], xb1[6], xb2[6];   // x windows  (rows r+1, r+2, r+3 of X)
-    read6(DT1 + r0i * LS, o, da0); read6(DT1 + (r0i + 1) * LS, o, da1);
-    read6(DT2 + r0i * LS, o, db0); read6(DT2 + (r0i + 1) * LS, o, db1);
-    read6(X1 + (r0i + 1) * LS, o, xa0); read6(X1 + (r0i + 2) * LS, o, xa1);
-    read6(X2 + (r0i + 1) * LS, o, xb0); read6(X2 + (r0i + 2) * LS, o, xb1);
-    for (int i = 0; i < a.SR; ++i) {
-      const int r = r0i + i, h = h0 + r;
-      if (h >= a.H) break;
-      read6(DT1 + (r + 2) * LS, o, da2);
-      read6(DT2 + (r + 2) * LS, o, db2);
-      read6(X1 + (r + 3) * LS, o, xa2);
-      read6(X2 + (r + 3) * LS, o, xb2);
-      float o1[4], o2[4];
-      conv4(da0, da1, da2, f1, o1);
-      conv4(db0, db1, db2, f2, o2);
-      float* p1 = a.dx + b * a.dx_bs + c * HW + (long)h * a.W + col;
-      f32x4 v1 = {o1[0], o1[1], o1[2], o1[3]}, v2 = {o2[0], o2[1], o2[2], o2[3]};
-      *reinterpret_cast<f32x4*>(p1) = v1;
-      *reinterpret_cast<f32x4*>(p1 + a.hid * HW) = v2;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+    for (int pl = 0; pl < 2; ++pl) {
+      const float* DT = pl ? DT2 : DT1;
+      const float* XP = pl ? X2 : X1;
+      const float (&ff)[9] = pl ? f2 : f1;
+      float (&wsum)[9] = pl ? ws2 : ws1;
+      float d0[6], d1[6], d2[6], x0[6], x1[6], x2[6];   // dt windows (rows r, r+1, r+2), x windows (rows r+1, r+2, r+3)
+      read6(DT + r0i * LS, o, d0); read6(DT + (r0i + 1) * LS, o, d1);
+      read6(XP + (r0i + 1) * LS, o, x0); read6(XP + (r0i + 2) * LS, o, x1);
+      for (int i = 0; i < a.SR; ++i) {
+        const int r = r0i + i, h = h0 + r;
+        if (h >= a.H) break;
+        read6(DT + (r + 2) * LS, o, d2);
+        read6(XP + (r + 3) * LS, o, x2);
+        float o1[4];
+        conv4(d0, d1, d2, ff, o1);
+        float* p1 = a.dx + b * a.dx_bs + (c + pl * a.hid) * HW + (long)h * a.W + col;
+        f32x4 v1 = {o1[0], o1[1], o1[2], o1[3]};
+        *reinterpret_cast<f32x4*>(p1) = v1;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          ws1[d] += da1[j + 1] * xa0[j + d]; ws1[3 + d] += da1[j + 1] * xa1[j + d]; ws1[6 + d] += da1[j + 1] * xa2[j + d];
-          ws2[d] += db1[j + 1] * xb0[j + d]; ws2[3 + d] += db1[j + 1] * xb1[j + d]; ws2[6 + d] += db1[j + 1] * xb2[j + d];
-        }
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        da0[j] = da1[j]; da1[j] = da2[j]; db0[j] = db1[j]; db1[j] = db2[j];
-        xa0[j] = xa1[j]; xa1[j] = xa2[j]; xb0[j] = xb1[j]; xb1[j] = xb2[j];
+          for (int d = 0; d < 3; ++d) {
+            wsum[d] += d1[j + 1] * x0[j + d]; wsum[3 + d] += d1[j + 1] * x1[j + d]; wsum[6 + d] += d1[j + 1] * x2[j + d];
+          }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { d0[j] = d1[j]; d1[j] = d2[j]; x0[j] = x1[j]; x1[j] = x2[j]; }
       }
     }
   }
