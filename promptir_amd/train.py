@@ -144,6 +144,11 @@ class DataParallelTrainer:
                 for i in range(n):
                     self._sinks[i].append((p, self._grads[i][o:o + p.numel()].view_as(p)))
 
+    def _use_sinks_default(self) -> None:
+        for n, p in self.opt.named:
+            o = self.opt.offsets[n]
+            p._grad_sink = self.opt.grad[o:o + p.numel()].view_as(p)
+
     def _use_sinks(self, which: int) -> None:
         for p, view in self._sinks[which]:
             p._grad_sink = view
@@ -202,18 +207,31 @@ class DataParallelTrainer:
             self._sloss = self._fwd_bwd(self._sx, self._st)
         self._graph_shape = tuple(degrad_patch.shape)
 
+    def _ensure_graph(self, degrad_patch: torch.Tensor, clean_patch: torch.Tensor) -> None:
+        if self._graph is not None and self._graph_shape == tuple(degrad_patch.shape):
+            return
+        try:
+            self._capture(degrad_patch, clean_patch)
+        except Exception as exc:   # e.g. a runtime that refuses the capture: keep training, eagerly on one stream
+            import warnings
+
+            warnings.warn(f"hipGraph capture failed ({exc!r}); falling back to the eager single-stream step")
+            torch.cuda.synchronize()
+            self.graph, self._graph, self.micro_streams = False, None, 1
+            self._use_sinks_default()
+
     def prepare(self, degrad_patch: torch.Tensor, clean_patch: torch.Tensor) -> None:
         """Optional: build the graph for this batch shape now (otherwise the first train_step does it)."""
-        if self.graph and degrad_patch.is_cuda and (self._graph is None or self._graph_shape != tuple(degrad_patch.shape)):
-            self._capture(degrad_patch, clean_patch)
+        if self.graph and degrad_patch.is_cuda:
+            self._ensure_graph(degrad_patch, clean_patch)
 
     def train_step(self, degrad_patch: torch.Tensor, clean_patch: torch.Tensor, lr: Optional[float] = None):
         """reference train.py:37-46 (+ optimizer.step of Lightning's loop)."""
         from . import ops
 
         if self.graph and degrad_patch.is_cuda and ops.lib.records is None:
-            if self._graph is None or self._graph_shape != tuple(degrad_patch.shape):
-                self._capture(degrad_patch, clean_patch)
+            self._ensure_graph(degrad_patch, clean_patch)
+        if self.graph and degrad_patch.is_cuda and ops.lib.records is None:
             self._sx.copy_(degrad_patch)
             self._st.copy_(clean_patch)
             self._graph.replay()
