@@ -56,7 +56,7 @@ struct X3Conv { int H, W, ksteps; unsigned magic_ks, magic_w; };
 // waves_per_eu: the 128-column tiles (<= 50 KB of LDS) fit three workgroups per CU once the compiler is told to
 // stay within 168 registers (it then also keeps the accumulators in VGPRs); the 256-column tiles run two.
 template <int TM, int TN, int WM, int WN, bool A_MFAST, bool A_PRE, bool CONV = false>
-__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu((WM == 2 && WN == 2 && (A_PRE || TM * TN <= 2)) ? 3 : 2)))
+__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(((WM == 2 && WN == 2 && (A_PRE || TM * TN <= 2)) || (TM == 3 && TN == 1 && A_PRE)) ? 3 : 2)))
 void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, T = WM * WN * 64;
   constexpr int AKS = BM + 4;              // 16-byte units between the two k-groups of A (+4: bank shift)
@@ -882,6 +882,7 @@ int pir_nn_x3_launch(const pir_gemm_nn_t* a, int cfg, hipStream_t s) {
       case 1: return launch_cfg<2, 2, 1, 4>(g, s);
       case 2: return launch_cfg<3, 2, 1, 4>(g, s);
       case 3: return launch_cfg<2, 2, 2, 2>(g, s);
+      case 7: return launch_cfg<3, 1, 1, 4>(g, s);   // 96 x 128
       default: return launch_cfg<1, 2, 2, 2>(g, s);
     }
   }
@@ -889,6 +890,11 @@ int pir_nn_x3_launch(const pir_gemm_nn_t* a, int cfg, hipStream_t s) {
   // row and stage) wins at the high-resolution levels even with up to ~13 % more padded rows.
   if (M <= 32) return launch_cfg<1, 2, 1, 4>(g, s);
   if (M <= 64) return g.K <= 64 ? launch_cfg<1, 2, 2, 2>(g, s) : launch_cfg<2, 2, 1, 4>(g, s);
+  // 96 x 128 (three workgroups per CU) for the GDFN project_in pair at the 96-channel levels: -6 ... -11 % there,
+  // neutral or worse for the other full-resolution shapes (tools/cfg7.py)
+  if (g.A3 && ((M >= 384 && g.K <= 128 && g.N >= 4096) || (g.K >= 384 && M == 96 && g.N >= 16384)) &&
+      pir_cdiv(M, 96) * 96 * 100 <= pir_cdiv(M, 128) * 128 * 113)
+    return launch_cfg<3, 1, 1, 4>(g, s);
   const long pad96 = pir_cdiv(M, 96) * 96, pad128 = pir_cdiv(M, 128) * 128;
   const bool use96 = g.N >= 1024 ? pad96 * 100 <= pad128 * 113 : pad96 < pad128;
   const long blocks = use96 ? pir_cdiv(M, 96) * pir_cdiv(g.N, 256) * batch : pir_cdiv(M, 128) * pir_cdiv(g.N, 128) * batch;
