@@ -65,6 +65,11 @@ typedef struct {
   const void* A3; int a3_kp;
 } pir_gemm_nn_t;
 int pir_gemm_nn(const pir_gemm_nn_t* args, pir_stream_t stream);
+/* Host-only query: which kernel instantiation pir_gemm_nn would launch for `args` (pointers are not dereferenced
+ * except A3 != NULL).  0 = plain fp32-MFMA kernel; otherwise the bf16x3 tile plan TM*1000 + TN*100 + WM*10 + WN
+ * (workgroup of WM x WN waves, each TM x TN 32x32 MFMA tiles: 3114 = 96 x 128, 3214 = 96 x 256, 2222 = 128 x 128,
+ * ...).  Negative on bad sizes.  Lets tests pin that a benchmarked shape reaches the instantiation tuned for it. */
+int pir_gemm_nn_plan(const pir_gemm_nn_t* args);
 /* out[part][k/16][m][k%16] (bf16, k padded with zeros to kp = multiple of 16) = part-th piece of the exact
  * split W(m,k) = hi + mid + lo with W(m,k) = W[m*sm + k*sk]; out holds 3*M*kp bf16.  The 16 k-values of one
  * matrix-core k-step are contiguous per row and rows are contiguous per k-step. Used once per weight
@@ -269,6 +274,19 @@ int pir_copy_planes(const float* x, long x_bs, float* y, long y_bs, int accumula
                     int B, long plane_floats, pir_stream_t stream);
 /* out[i] = a[i] + b[i] */
 int pir_add(const float* a, const float* b, float* out, long count, pir_stream_t stream);
+
+/* Convolution bias, `bias=True` (net/model.py:88-92,111-113,206,294-320; every reference caller passes False):
+ *   pir_bias_add   y[b][c][:] += bias[c] in place (after the bias-free convolution kernel)
+ *   pir_bias_grad  db[c] = sum_{b,p} dy[b][c][p] (the bias gradient autograd derives for nn.Conv2d)
+ * and the GELU gate of FeedForward (:96-97) as a stand-alone pair, for the biased GDFN where the depthwise bias
+ * sits between the stencil and the gate (the bias-free path uses the fused pir_dwconv3x3_gate instead):
+ *   pir_gelu_gate      g = gelu_erf(t[:, :hid]) * t[:, hid:]
+ *   pir_gelu_gate_bwd  dt[:, :hid] = dg * t[:, hid:] * gelu'(t[:, :hid]);  dt[:, hid:] = dg * gelu(t[:, :hid]) */
+int pir_bias_add(float* y, long y_bs, const float* bias, int B, int C, int HW, pir_stream_t stream);
+int pir_bias_grad(const float* dy, long dy_bs, float* db, int B, int C, int HW, pir_stream_t stream);
+int pir_gelu_gate(const float* t, long t_bs, float* g, long g_bs, int B, int hid, int HW, pir_stream_t stream);
+int pir_gelu_gate_bwd(const float* t, long t_bs, const float* dg, long dg_bs, float* dt, long dt_bs,
+                      int B, int hid, int HW, pir_stream_t stream);
 /* out[j] = alpha * sum_{s<S} parts[s*stride + j] (+ out[j] if accumulate) */
 int pir_reduce_partials(const float* parts, long stride, int S, float alpha, int accumulate,
                         float* out, long count, pir_stream_t stream);

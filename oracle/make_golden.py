@@ -32,6 +32,22 @@ sys.path.insert(0, REF)
 
 from promptir_amd import weights as W  # noqa: E402
 
+
+def _reference(relpath: str):
+    """Load a module of the REAL reference by file path.  (`import net.model` would resolve to this repo's own
+    drop-in `net/` package: a regular package shadows the reference's namespace package whatever sys.path says.)"""
+    import importlib.util
+
+    name = "reference_" + relpath.replace("/", "_").removesuffix(".py")
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    assert os.path.realpath(mod.__file__).startswith(REF + "/"), mod.__file__
+    return mod
+
 OUT = os.path.join(REPO, "tests", "golden")
 FULL_GRAD_MAX = 4096
 
@@ -65,7 +81,7 @@ def grad_summary(named_params, out: dict, tag: str) -> None:
 
 
 def model_case(fname, ctor_kwargs, batch, height, width, sigma, seed, with_backward=True):
-    from net.model import PromptIR  # the real reference
+    PromptIR = _reference("net/model.py").PromptIR  # the real reference
 
     torch.manual_seed(0)
     net = PromptIR(**ctor_kwargs)
@@ -89,6 +105,63 @@ def model_case(fname, ctor_kwargs, batch, height, width, sigma, seed, with_backw
     print(fname, "y", tuple(y.shape), "absmax", float(y.abs().max()))
 
 
+def model_case_chunked(fname, ctor_kwargs, batch, chunk, height, width, sigmas, seed):
+    """Loss + gradient summaries of a batch too large to run through the reference in one piece in this
+    container (64 GiB, no swap): no op of the network mixes samples and nn.L1Loss is a mean over all elements, so
+    loss_B = sum_c (n_c / B) loss_c and the gradients add the same way.  The real reference runs on `chunk`
+    samples at a time, each chunk's loss scaled by n_c / B before backward(); autograd accumulates in .grad.
+    Inputs are not stored: tests rebuild them with W.synthetic_pair(batch, ..., sigma=sigmas, seed=seed)."""
+    PromptIR = _reference("net/model.py").PromptIR  # the real reference
+
+    net = PromptIR(**ctor_kwargs)
+    load_generated(net, seed)
+    degraded, clean = W.synthetic_pair(batch, height, width, sigma=sigmas, seed=seed)
+    total = 0.0
+    ysum = []
+    for lo in range(0, batch, chunk):
+        x = torch.from_numpy(degraded[lo:lo + chunk])
+        t = torch.from_numpy(clean[lo:lo + chunk])
+        y = net(x)
+        loss = torch.nn.L1Loss()(y, t) * (x.shape[0] / batch)
+        loss.backward()
+        total += float(loss.detach().double())
+        ysum += [float(v) for v in y.detach().double().sum(dim=(1, 2, 3))]
+        del y, loss
+    out = {"ctor": np.array(json.dumps(ctor_kwargs)), "seed": np.array(seed), "batch": np.array(batch),
+           "size": np.array([height, width]), "sigmas": np.array(sigmas, dtype=np.int64),
+           "loss": np.array(total, dtype=np.float64), "y_sum": np.array(ysum, dtype=np.float64)}
+    grad_summary(list(net.named_parameters()), out, "")
+    for k in [k for k in out if k.startswith("grad/")]:   # summaries only: keep the fixture small
+        if out[k].size > 256:
+            del out[k]
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, "loss", total)
+
+
+def bench_loss_case():
+    """Step-1 L1 loss of bench.py's synthetic batches through the REAL reference (forward only, 8 patches at a
+    time): weights seed 0; inputs W.synthetic_pair(B, 128, 128, sigma mix, seed=100 + rank).  bench.py asserts
+    its first training step reproduces these (config 3: batch 32, rank 0; config 5: batch 8, ranks 0..7)."""
+    PromptIR = _reference("net/model.py").PromptIR
+
+    net = PromptIR(decoder=True)
+    load_generated(net, 0)
+    out = {}
+    with torch.no_grad():
+        for batch, ranks in ((32, (0,)), (8, tuple(range(8)))):
+            for rank in ranks:
+                sigmas = [(15, 25, 50)[i % 3] for i in range(batch)]
+                degraded, clean = W.synthetic_pair(batch, 128, 128, sigma=sigmas, seed=100 + rank)
+                tot = 0.0
+                for lo in range(0, batch, 8):
+                    y = net(torch.from_numpy(degraded[lo:lo + 8]))
+                    tot += float((y - torch.from_numpy(clean[lo:lo + 8])).abs().double().sum())
+                out[f"b{batch}_rank{rank}"] = tot / (batch * 3 * 128 * 128)
+                print("bench loss", batch, rank, out[f"b{batch}_rank{rank}"])
+    with open(os.path.join(OUT, "bench_step1_loss.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def module_case(store, tag, module, x_shape, seed, call=None):
     load_generated(module, seed, prefix=tag + "/")
     n = int(np.prod(x_shape))
@@ -108,7 +181,7 @@ def module_case(store, tag, module, x_shape, seed, call=None):
 
 
 def modules():
-    import net.model as R
+    R = _reference("net/model.py")
 
     store = {}
     seed = 7
@@ -136,7 +209,7 @@ def modules():
 def tile_case():
     """Reference model under the restated demo.py tile harness (demo.py itself needs
     `lightning`, which is not installed, so the harness is oracle.tile_eval)."""
-    from net.model import PromptIR
+    PromptIR = _reference("net/model.py").PromptIR
     from oracle.promptir_ref import tile_eval
 
     kwargs = dict(decoder=True, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1)
@@ -151,7 +224,7 @@ def tile_case():
 
 
 def scheduler_case():
-    from utils.schedulers import LinearWarmupCosineAnnealingLR
+    LinearWarmupCosineAnnealingLR = _reference("utils/schedulers.py").LinearWarmupCosineAnnealingLR
 
     lin = torch.nn.Linear(2, 2)
     opt = torch.optim.AdamW(lin.parameters(), lr=2e-4)
@@ -168,7 +241,7 @@ def scheduler_case():
 
 def structure_case():
     """Known-answer structure facts of the default network."""
-    from net.model import PromptIR
+    PromptIR = _reference("net/model.py").PromptIR
 
     net = PromptIR(decoder=True)
     sd = net.state_dict()
@@ -202,6 +275,24 @@ def main():
     if want("full"):
         model_case("model_full_64.npz", dict(decoder=True), 1, 64, 64, 25, 0)
         model_case("model_full_128.npz", dict(decoder=True), 1, 128, 128, 25, 5, with_backward=False)
+    if want("bias"):   # bias=True (net/model.py:253): never used by the reference's callers, part of the ctor surface
+        model_case("model_small_64_bias.npz", dict(small, bias=True), 1, 64, 64, 25, 12)
+        R = _reference("net/model.py")
+        store = {}
+        module_case(store, "attn_48_1_bias", R.Attention(48, 1, True), (2, 48, 12, 16), 7)
+        module_case(store, "ffn_48_bias", R.FeedForward(48, 2.66, True), (2, 48, 12, 16), 7)
+        module_case(store, "tblock_96_2_bias", R.TransformerBlock(96, 2, 2.66, True, "WithBias"), (1, 96, 8, 16), 7)
+        np.savez_compressed(os.path.join(OUT, "modules_bias.npz"), **store)
+        net = R.PromptIR(decoder=True, bias=True)
+        with open(os.path.join(OUT, "state_dict_shapes_bias.json"), "w") as f:
+            json.dump({"keys": list(net.state_dict().keys()),
+                       "num_params": sum(p.numel() for p in net.parameters())}, f)
+    if want("benchloss"):
+        bench_loss_case()
+    if want("config3"):   # BASELINE config 3 shapes (128x128, full depth) WITH backward
+        model_case("model_full_128_bwd.npz", dict(decoder=True), 2, 128, 128, [25, 50], 6)
+        model_case_chunked("model_full_128_b16.npz", dict(decoder=True), 16, 4, 128, 128,
+                           [(15, 25, 50)[i % 3] for i in range(16)], 8)
 
 
 if __name__ == "__main__":

@@ -142,7 +142,8 @@ def prompt_gen(x: torch.Tensor, p: Params) -> torch.Tensor:
 def promptir_forward(params: Params, inp_img: torch.Tensor, heads: Sequence[int] = (1, 2, 4, 8),
                      decoder: bool = True) -> torch.Tensor:
     """net/model.py:322-380.  `heads[2]` is used for all three noise_level blocks
-    (net/model.py:295,304,312)."""
+    (net/model.py:295,304,312).  The `.bias` entries exist only for PromptIR(bias=True) (:253; patch_embed, the
+    Down/Upsample and PromptGenBlock convolutions are always bias-free, :164,174,206,223,259)."""
     P = params
     enc1_in = F.conv2d(inp_img, P["patch_embed.proj.weight"], None, padding=1)        # :324
     enc1 = _stage(enc1_in, P, "encoder_level1", heads[0])                              # :326
@@ -152,25 +153,25 @@ def promptir_forward(params: Params, inp_img: torch.Tensor, heads: Sequence[int]
     if decoder:                                                                        # :339-343
         latent = torch.cat([latent, prompt_gen(latent, _sub(P, "prompt3"))], 1)
         latent = transformer_block(latent, _sub(P, "noise_level3"), heads[2])
-        latent = F.conv2d(latent, P["reduce_noise_level3.weight"])
+        latent = F.conv2d(latent, P["reduce_noise_level3.weight"], P.get("reduce_noise_level3.bias"))
     d3 = torch.cat([upsample(latent, _sub(P, "up4_3")), enc3], 1)                       # :346-347
-    d3 = F.conv2d(d3, P["reduce_chan_level3.weight"])                                   # :348
+    d3 = F.conv2d(d3, P["reduce_chan_level3.weight"], P.get("reduce_chan_level3.bias"))                                   # :348
     d3 = _stage(d3, P, "decoder_level3", heads[2])                                      # :350
     if decoder:                                                                        # :351-355
         d3 = torch.cat([d3, prompt_gen(d3, _sub(P, "prompt2"))], 1)
         d3 = transformer_block(d3, _sub(P, "noise_level2"), heads[2])
-        d3 = F.conv2d(d3, P["reduce_noise_level2.weight"])
+        d3 = F.conv2d(d3, P["reduce_noise_level2.weight"], P.get("reduce_noise_level2.bias"))
     d2 = torch.cat([upsample(d3, _sub(P, "up3_2")), enc2], 1)                           # :358-359
-    d2 = F.conv2d(d2, P["reduce_chan_level2.weight"])                                   # :360
+    d2 = F.conv2d(d2, P["reduce_chan_level2.weight"], P.get("reduce_chan_level2.bias"))                                   # :360
     d2 = _stage(d2, P, "decoder_level2", heads[1])                                      # :362
     if decoder:                                                                        # :363-367
         d2 = torch.cat([d2, prompt_gen(d2, _sub(P, "prompt1"))], 1)
         d2 = transformer_block(d2, _sub(P, "noise_level1"), heads[2])
-        d2 = F.conv2d(d2, P["reduce_noise_level1.weight"])
+        d2 = F.conv2d(d2, P["reduce_noise_level1.weight"], P.get("reduce_noise_level1.bias"))
     d1 = torch.cat([upsample(d2, _sub(P, "up2_1")), enc1], 1)                           # :369-370
     d1 = _stage(d1, P, "decoder_level1", heads[0])                                      # :372
     d1 = _stage(d1, P, "refinement", heads[0])                                          # :374
-    return F.conv2d(d1, P["output.weight"], None, padding=1) + inp_img                 # :377
+    return F.conv2d(d1, P["output.weight"], P.get("output.bias"), padding=1) + inp_img                 # :377
 
 
 def l1_loss(restored: torch.Tensor, clean: torch.Tensor) -> torch.Tensor:

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PIR_LIB", os.path.join(_HERE, "libpromptir_hip.so"))  # PIR_LIB: A/B builds in tools/
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_float_p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 c_long = C.c_long
@@ -58,6 +58,7 @@ SIGNATURES = {
     "pir_arch": (C.c_char_p, []),
     "pir_tune_set": (I, [I, I]),
     "pir_gemm_nn": (I, [C.POINTER(GemmNN), S]),
+    "pir_gemm_nn_plan": (I, [C.POINTER(GemmNN)]),
     "pir_split_bf16x3_bytes": (Z, [I, I]),
     "pir_split_bf16x3": (I, [P, I, I, L, L, P, S]),
     "pir_conv3x3": (I, [P, L, L, L, I, P, L, P, L, P, L, I, I, I, I, I, S]),
@@ -98,6 +99,10 @@ SIGNATURES = {
     "pir_degrade_gaussian": (I, [P, P, P, P, L, I, S]),
     "pir_copy_planes": (I, [P, L, P, L, I, I, L, S]),
     "pir_add": (I, [P, P, P, L, S]),
+    "pir_bias_add": (I, [P, L, P, I, I, I, S]),
+    "pir_bias_grad": (I, [P, L, P, I, I, I, S]),
+    "pir_gelu_gate": (I, [P, L, P, L, I, I, I, S]),
+    "pir_gelu_gate_bwd": (I, [P, L, P, L, P, L, I, I, I, S]),
     "pir_reduce_partials": (I, [P, L, I, F, I, P, L, S]),
     "pir_adamw_step": (I, [P, P, P, P, L, F, F, F, F, F, L, F, S]),
 }

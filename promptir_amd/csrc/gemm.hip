@@ -863,6 +863,11 @@ extern "C" int pir_tune_set(int knob, int value) {
   }
 }
 
+extern "C" int pir_gemm_nn_plan(const pir_gemm_nn_t* a) {
+  if (!a || a->M <= 0 || a->K <= 0 || a->N <= 0 || a->O1 <= 0 || a->O2 <= 0) return PIR_EINVAL;
+  return pir_nn_x3_wanted(a, g_nn_x3) ? pir_nn_x3_plan(a, g_nn_cfg) : 0;
+}
+
 extern "C" int pir_gemm_nn(const pir_gemm_nn_t* a, pir_stream_t stream) {
   PIR_CHECK_ARG(a && a->A && a->X && a->Y);
   PIR_CHECK_ARG(a->M > 0 && a->K > 0 && a->N > 0 && a->O1 > 0 && a->O2 > 0);

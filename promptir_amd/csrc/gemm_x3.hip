@@ -13,9 +13,6 @@
 // holds A[row r][k = 8h + j] and B[k = 8h + j][col r], j = 0..7  => one 16-byte LDS read per fragment from a
 // [k-group][row][8 x bf16] image.  The split happens when a stage is written to LDS.
 #include "gemm_common.h"
-#ifndef PP_STAGE_PRIO
-#define PP_STAGE_PRIO 0   // wave priority of the ping-pong kernel's staging phase (experiment knob)
-#endif
 #ifndef X3_MFMA_PRIO
 #define X3_MFMA_PRIO 0   // experiment knob: > 0 raises the wave priority around the MFMA cluster, < 0 raises it everywhere else
 #endif
@@ -286,444 +283,6 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
   pir_nn_epilogue<TM, TN>(acc, g, Y, o1, o2, m0, n0, wm, wn, lane);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Ping-pong variant for pre-split weights (A3): one persistent 8-wave workgroup per CU, tile 128 x 256.
-// The two 4-wave halves ("ping": rows 0-63, "pong": rows 64-127 of the tile; each wave 64 x 64) alternate
-// between a matrix phase (24 MFMAs on the stage that is two steps old) and a staging phase (split the
-// freshly arrived fp32 activations to bf16x3, write them to a 3-deep LDS ring, issue the global loads of
-// four stages ahead, pre-read the next fragments).  The two workgroup barriers per k-step keep the halves
-// in opposite phases, so on every SIMD one wave feeds the matrix pipe while its partner does the VALU /
-// LDS / VMEM work.  The stage stream runs across tile boundaries (tiles b, b+G, ... of workgroup b), so the
-// loads of the next tile are in flight while the current one finishes: no per-tile prologue bubble.
-//
-// Activations are read with 16-byte loads along the pixel axis (one wave = one 1 KB row segment; per-lane
-// 4-byte gathers cost the same vector-memory issue slots for a quarter of the bytes and were the bottleneck),
-// stored row-major [k][pixel] in LDS and transposed into the k-contiguous MFMA B operand by
-// ds_read_b64_tr_b16 (cdna_hip_programming.md T10).
-constexpr int PP_BM = 128, PP_BN = 256;
-constexpr int PP_AKS = PP_BM + 4;                        // 16-byte units between the two k-groups of A
-constexpr int PP_BRS = PP_BN + 32;                       // B row stride (bf16): 576 B puts 4 rows on disjoint banks
-constexpr int PP_A_BYTES = 2 * PP_AKS * 16, PP_B_BYTES = 16 * PP_BRS * 2;
-constexpr int PP_PART_BYTES = PP_A_BYTES + PP_B_BYTES, PP_STAGE_BYTES = 3 * PP_PART_BYTES;
-
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
-
-struct PPRegs { f32x4 b[2]; bf16x8 a[2]; };
-struct PPFrags { bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2]; };
-
-__device__ __forceinline__ void split4(const f32x4& v, bf16x4& hi, bf16x4& mid, bf16x4& lo) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float x = v[j];
-    const __bf16 h = (__bf16)x;
-    const float r1 = x - (float)h;
-    const __bf16 m = (__bf16)r1;
-    const float r2 = r1 - (float)m;
-    hi[j] = h; mid[j] = m; lo[j] = (__bf16)r2;
-  }
-}
-
-// transposed 8-byte LDS read: lane i of each 16-lane group receives column i of the 4 rows addressed by the group
-__device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p, int row4_bytes) {
-  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
-  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + row4_bytes));
-  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
-}
-
-__global__ __launch_bounds__(512) void gemm_nn_pp_kernel(pir_gemm_nn_t g, int tiles_m, int tiles_n, int total) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * PP_STAGE_BYTES];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wid >> 2, wq = wid & 3, tg = tid & 255;
-  const int iters = (g.K + XK - 1) / XK;
-  const int G = gridDim.x, bid = blockIdx.x;
-  const int my_tiles = (total - bid + G - 1) / G;
-  const int S = my_tiles * iters;
-  const int ldx4 = (int)g.ldx * 4;
-  const int a3_part_bytes = g.M * g.a3_kp * 2, a3_step_bytes = g.M * 32;
-  const __amdgpu_buffer_rsrc_t ars = pir_make_rsrc(g.A3, (unsigned)(6L * g.M * g.a3_kp));
-  const unsigned x_bytes = (unsigned)((((long)g.K - 1) * g.ldx + g.N) * 4);
-
-  // staging roles inside a half (256 threads): B rows 8*grp + wq and + 4 (one wave = one 256-pixel row);
-  // A: the half's own 64 rows, both k-groups (lanes 2r, 2r+1 = row r: a wave reads 1 KB contiguous);
-  // threads 0-127 carry parts hi and lo, threads 128-255 part mid
-  const int a_row = grp * 64 + ((tg & 127) >> 1), a_kg = tg & 1;
-  const int a_part0 = __builtin_amdgcn_readfirstlane(tg >> 7);   // 0 -> parts {0, 2}, 1 -> part {1}
-  const int b_row = 8 * grp + wq;
-
-  auto tile_coords = [&](int ord, int& m0, int& n0, int& o) __attribute__((always_inline)) {
-    const int t = pir_xcd_remap(ord * G + bid, total);
-    m0 = (t % tiles_m) * PP_BM;
-    const int rest = t / tiles_m;
-    n0 = (rest % tiles_n) * PP_BN;
-    o = rest / tiles_n;
-  };
-
-  // ---- load cursor
-  int l_ord = 0, l_k = 0, b_voff = 0, a_voff = 0;
-  __amdgpu_buffer_rsrc_t xrs = ars;
-  auto set_load_tile = [&](int ord) __attribute__((always_inline)) {
-    int m0, n0, o;
-    tile_coords(ord, m0, n0, o);
-    const int o1 = o / g.O2, o2 = o % g.O2;
-    xrs = pir_make_rsrc(g.X + o1 * g.x_s1 + o2 * g.x_s2, x_bytes);
-    b_voff = (n0 + lane * 4) * 4;
-    const int m = m0 + a_row, mc = m < g.M ? m : g.M - 1;
-    a_voff = (mc * 16 + 8 * a_kg) * 2;
-  };
-  set_load_tile(0);
-  // Unconditional on purpose (see gemm_nn_x3_kernel): past the last stage the cursor stays on it and the
-  // re-loaded data is never used, so the compiler can count the loads in flight exactly.
-  auto issue = [&](PPRegs& R) __attribute__((always_inline)) {
-    const int k0 = l_k * XK;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      R.b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, b_voff, (k0 + b_row + 4 * i) * ldx4, 0));
-    R.a[0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                                            ars, a_voff, a_part0 * a3_part_bytes + l_k * a3_step_bytes, 0));
-    R.a[1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                                            ars, a_voff, 2 * a3_part_bytes + l_k * a3_step_bytes, 0));
-    if (l_k + 1 < iters) {
-      ++l_k;
-    } else if (l_ord + 1 < my_tiles) {
-      l_k = 0;
-      set_load_tile(++l_ord);
-    }
-  };
-  auto stash = [&](int buf, const PPRegs& R) __attribute__((always_inline)) {
-    unsigned char* base = smem + buf * PP_STAGE_BYTES;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      bf16x4 hi, mid, lo;
-      split4(R.b[i], hi, mid, lo);
-      unsigned char* q = base + PP_A_BYTES + ((b_row + 4 * i) * PP_BRS + lane * 4) * 2;
-      *reinterpret_cast<bf16x4*>(q) = hi;
-      *reinterpret_cast<bf16x4*>(q + PP_PART_BYTES) = mid;
-      *reinterpret_cast<bf16x4*>(q + 2 * PP_PART_BYTES) = lo;
-    }
-    unsigned char* qa = base + (a_kg * PP_AKS + a_row) * 16;
-    if (a_part0 == 0) {
-      *reinterpret_cast<bf16x8*>(qa) = R.a[0];
-      *reinterpret_cast<bf16x8*>(qa + 2 * PP_PART_BYTES) = R.a[1];
-    } else {
-      *reinterpret_cast<bf16x8*>(qa + PP_PART_BYTES) = R.a[0];
-    }
-  };
-  const int fr_h = lane >> 5, fr_r = lane & 31;
-  const int tr_off = PP_A_BYTES + ((8 * fr_h + ((lane & 15) >> 2)) * PP_BRS + wq * 64 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-  auto read_frags = [&](int buf, PPFrags& F) __attribute__((always_inline)) {
-    const unsigned char* base = smem + buf * PP_STAGE_BYTES;
-    const unsigned char* ap = base + (fr_h * PP_AKS + grp * 64 + fr_r) * 16;
-    const unsigned char* bp = base + tr_off;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      F.ah[i] = *reinterpret_cast<const bf16x8*>(ap + i * 512);
-      F.am[i] = *reinterpret_cast<const bf16x8*>(ap + PP_PART_BYTES + i * 512);
-      F.al[i] = *reinterpret_cast<const bf16x8*>(ap + 2 * PP_PART_BYTES + i * 512);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      F.bh[j] = tr_read8(bp + j * 64, 4 * PP_BRS * 2);
-      F.bm[j] = tr_read8(bp + PP_PART_BYTES + j * 64, 4 * PP_BRS * 2);
-      F.bl[j] = tr_read8(bp + 2 * PP_PART_BYTES + j * 64, 4 * PP_BRS * 2);
-    }
-  };
-
-  f32x16 acc[2][2];
-  auto zero_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  };
-  zero_acc();
-  int c_ord = 0, c_k = 0;
-  auto matrix_phase = [&](const PPFrags& F) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        f32x16 c = acc[i][j];
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.al[i], F.bh[j], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.ah[i], F.bl[j], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.am[i], F.bm[j], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.am[i], F.bh[j], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.ah[i], F.bm[j], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.ah[i], F.bh[j], c, 0, 0, 0);
-        acc[i][j] = c;
-      }
-    if (++c_k == iters && c_ord < my_tiles) {   // tile finished: store this half's 64 rows
-      int m0, n0, o;
-      tile_coords(c_ord, m0, n0, o);
-      const int o1 = o / g.O2, o2 = o % g.O2;
-      float* __restrict__ Y = g.Y + o1 * g.y_s1 + o2 * g.y_s2;
-      pir_nn_epilogue<2, 2>(acc, g, Y, o1, o2, m0 + grp * 64, n0, 0, wq, lane);
-      zero_acc();
-      c_k = 0;
-      ++c_ord;
-    }
-  };
-
-  PPRegs R0, R1, R2, R3;   // stage t travels in R[t & 3]: loaded 4 steps before it is staged, staged 2 before use
-  PPFrags F;
-  issue(R0); issue(R1);
-  stash(0, R0); stash(1, R1);
-  issue(R2); issue(R3); issue(R0); issue(R1);
-  __syncthreads();
-  int cbuf = 0, sbuf = 2;
-  auto advance = [&]() __attribute__((always_inline)) {
-    cbuf = cbuf == 2 ? 0 : cbuf + 1;
-    sbuf = sbuf == 2 ? 0 : sbuf + 1;
-  };
-  // the compiler may move MFMAs (register-only) across s_barrier, which would put both halves' matrix
-  // phases side by side: pin the phase boundaries
-  auto phase_barrier = [&]() __attribute__((always_inline)) {
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  // The two halves run separate, branch-free step sequences (two barriers per step each, so the barrier
-  // counts match); steps go in fours so that the register sets are compile-time names; a stage count that
-  // is not a multiple of four just runs up to three dummy steps on stale data.
-  if (grp == 0) {
-    read_frags(0, F);
-    auto ping = [&](PPRegs& R) __attribute__((always_inline)) {
-      matrix_phase(F);
-      phase_barrier();
-      __builtin_amdgcn_s_setprio(PP_STAGE_PRIO);
-      stash(sbuf, R);
-      issue(R);
-      read_frags(cbuf == 2 ? 0 : cbuf + 1, F);
-      __builtin_amdgcn_s_setprio(0);
-      phase_barrier();
-      advance();
-    };
-    for (int s = 0; s < S; s += 4) { ping(R2); ping(R3); ping(R0); ping(R1); }
-  } else {
-    auto pong = [&](PPRegs& R) __attribute__((always_inline)) {
-      __builtin_amdgcn_s_setprio(PP_STAGE_PRIO);
-      stash(sbuf, R);
-      issue(R);
-      read_frags(cbuf, F);
-      __builtin_amdgcn_s_setprio(0);
-      phase_barrier();
-      matrix_phase(F);
-      phase_barrier();
-      advance();
-    };
-    for (int s = 0; s < S; s += 4) { pong(R2); pong(R3); pong(R0); pong(R1); }
-  }
-}
-
-int launch_pp(const pir_gemm_nn_t& g, hipStream_t s) {
-  const int tiles_m = (int)pir_cdiv(g.M, PP_BM), tiles_n = (int)pir_cdiv(g.N, PP_BN);
-  const long total = (long)tiles_m * tiles_n * g.O1 * g.O2;
-  const int grid = total < PIR_NUM_CU ? (int)total : PIR_NUM_CU;   // PIR_NUM_CU is a multiple of the XCD count
-  hipLaunchKernelGGL(gemm_nn_pp_kernel, dim3(grid), dim3(512), 0, s, g, tiles_m, tiles_n, (int)total);
-  return pir_launch_status();
-}
-
-// ---------------------------------------------------------------------------------------------------
-// "Convert at read" variant for pre-split weights: one persistent 8-wave workgroup per CU, tile 128 x 256,
-// every wave 64 x 64.  Global -> LDS copies are LDS-DMA (buffer_load ... lds, 16 bytes per lane): the fp32
-// activation rows and the bf16 weight pieces land in a 4-deep LDS ring without touching VGPRs, three stages
-// ahead.  There is no staging phase: each wave reads the raw fp32 values of ITS OWN B fragments of the NEXT
-// stage, splits them to bf16x3 in registers and reads its A fragments while the matrix pipe works on the
-// current stage (the conversion VALU ops are fillers in the shadow of the 32-cycle MFMAs).  One barrier per
-// k-step; the stage stream runs across tile boundaries as in the ping-pong kernel.
-constexpr int CR_BM = 128, CR_BN = 256, CR_RING = 4;
-constexpr int CR_A_BYTES = 3 * 2 * CR_BM * 16;     // [part][k-group][row] 16-byte units
-constexpr int CR_B_BYTES = XK * CR_BN * 4;         // [k][column] fp32
-constexpr int CR_STAGE = CR_A_BYTES + CR_B_BYTES;
-typedef __attribute__((address_space(3))) void* cr_lds_ptr;
-
-struct CRFrags { bf16x8 a[2][3], b[2][3]; };
-
-__global__ __launch_bounds__(512) void gemm_nn_cr_kernel(pir_gemm_nn_t g, int tiles_m, int tiles_n, int total) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[CR_RING * CR_STAGE];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 2, wn = wid & 3;
-  const int iters = (g.K + XK - 1) / XK;
-  const int G = gridDim.x, bid = blockIdx.x;
-  const int my_tiles = (total - bid + G - 1) / G;
-  const int S = my_tiles * iters;
-  const int ldx4 = (int)g.ldx * 4;
-  const int a3_part_bytes = g.M * g.a3_kp * 2, a3_step_bytes = g.M * 32;
-  const __amdgpu_buffer_rsrc_t ars = pir_make_rsrc(g.A3, (unsigned)(6L * g.M * g.a3_kp));
-  const unsigned x_bytes = (unsigned)((((long)g.K - 1) * g.ldx + g.N) * 4);
-
-  // DMA roles of a wave, four 1 KB copies per stage: B rows 2*wid and 2*wid+1; A chunks q0 = wid and q1 = 8 + (wid & 3)
-  // (chunk q: part q/4, k-group (q>>1)&1, rows (q&1)*64 .. +63; waves 4-7 repeat chunks 8-11 so that every wave
-  // has exactly four loads per stage in flight and the vmcnt waits below are the same for all)
-  const int q0 = wid, q1 = 8 + (wid & 3);
-  auto chunk_lds = [&](int q) __attribute__((always_inline)) { return (((q >> 2) * 2 + ((q >> 1) & 1)) * CR_BM + (q & 1) * 64) * 16; };
-
-  auto tile_coords = [&](int ord, int& m0, int& n0, int& o) __attribute__((always_inline)) {
-    const int t = pir_xcd_remap(ord * G + bid, total);
-    m0 = (t % tiles_m) * CR_BM;
-    const int rest = t / tiles_m;
-    n0 = (rest % tiles_n) * CR_BN;
-    o = rest / tiles_n;
-  };
-
-  int l_ord = 0, l_k = 0, b_voff = 0, a_voff0 = 0, a_voff1 = 0;
-  __amdgpu_buffer_rsrc_t xrs = ars;
-  auto set_load_tile = [&](int ord) __attribute__((always_inline)) {
-    int m0, n0, o;
-    tile_coords(ord, m0, n0, o);
-    const int o1 = o / g.O2, o2 = o % g.O2;
-    xrs = pir_make_rsrc(g.X + o1 * g.x_s1 + o2 * g.x_s2, x_bytes);
-    b_voff = (n0 + lane * 4) * 4;
-    const int r0 = m0 + (q0 & 1) * 64 + lane, r1 = m0 + (q1 & 1) * 64 + lane;
-    a_voff0 = ((r0 < g.M ? r0 : g.M - 1) * 16 + 8 * ((q0 >> 1) & 1)) * 2;
-    a_voff1 = ((r1 < g.M ? r1 : g.M - 1) * 16 + 8 * ((q1 >> 1) & 1)) * 2;
-  };
-  set_load_tile(0);
-  // always four copies (past the last stage the cursor stays put and the ring slot it refills is never read)
-  auto issue = [&](int buf) __attribute__((always_inline)) {
-    unsigned char* st = smem + buf * CR_STAGE;
-    const int k0 = l_k * XK;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (cr_lds_ptr)(st + CR_A_BYTES + (2 * wid) * (CR_BN * 4)), 16, b_voff,
-                                             (k0 + 2 * wid) * ldx4, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (cr_lds_ptr)(st + CR_A_BYTES + (2 * wid + 1) * (CR_BN * 4)), 16, b_voff,
-                                             (k0 + 2 * wid + 1) * ldx4, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (cr_lds_ptr)(st + chunk_lds(q0)), 16, a_voff0,
-                                             (q0 >> 2) * a3_part_bytes + l_k * a3_step_bytes, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (cr_lds_ptr)(st + chunk_lds(q1)), 16, a_voff1,
-                                             (q1 >> 2) * a3_part_bytes + l_k * a3_step_bytes, 0, 0);
-  };
-  auto advance_cursor = [&]() __attribute__((always_inline)) {   // kept out of the MFMA block (it branches)
-    if (l_k + 1 < iters) {
-      ++l_k;
-    } else if (l_ord + 1 < my_tiles) {
-      l_k = 0;
-      set_load_tile(++l_ord);
-    }
-  };
-
-  const int fr_h = lane >> 5, fr_r = lane & 31;
-  auto read_a = [&](int buf, CRFrags& F) __attribute__((always_inline)) {
-    const unsigned char* ap = smem + buf * CR_STAGE + (fr_h * CR_BM + wm * 64 + fr_r) * 16;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int part = 0; part < 3; ++part)
-        F.a[i][part] = *reinterpret_cast<const bf16x8*>(ap + (part * 2 * CR_BM + i * 32) * 16);
-  };
-  auto read_b_raw = [&](int buf, float (&raw)[2][8]) __attribute__((always_inline)) {
-    const float* bp = reinterpret_cast<const float*>(smem + buf * CR_STAGE + CR_A_BYTES) + 8 * fr_h * CR_BN + wn * 64 + fr_r;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int t = 0; t < 8; ++t) raw[j][t] = bp[t * CR_BN + j * 32];
-  };
-  auto convert_b = [&](const float (&raw)[2][8], CRFrags& F) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const Frag3 fr = split8(raw[j], true);
-      F.b[j][0] = fr.hi; F.b[j][1] = fr.mid; F.b[j][2] = fr.lo;
-    }
-  };
-
-  f32x16 acc[2][2];
-  auto zero_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  };
-  zero_acc();
-  int c_ord = 0, c_k = 0;
-  auto matrix = [&](const CRFrags& F) __attribute__((always_inline)) {
-    // term-major: consecutive MFMAs go to different accumulators; F.a/F.b parts: 0 hi, 1 mid, 2 lo
-#define PIR_CR_TERM(PA, PB)                                                                  \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][PA], F.b[j][PB], acc[i][j], 0, 0, 0);
-    PIR_CR_TERM(2, 0)
-    PIR_CR_TERM(0, 2)
-    PIR_CR_TERM(1, 1)
-    PIR_CR_TERM(1, 0)
-    PIR_CR_TERM(0, 1)
-    PIR_CR_TERM(0, 0)
-#undef PIR_CR_TERM
-  };
-  auto tile_end = [&]() __attribute__((always_inline)) {
-    if (++c_k == iters && c_ord < my_tiles) {
-      int m0, n0, o;
-      tile_coords(c_ord, m0, n0, o);
-      const int o1 = o / g.O2, o2 = o % g.O2;
-      float* __restrict__ Y = g.Y + o1 * g.y_s1 + o2 * g.y_s2;
-      pir_nn_epilogue<2, 2>(acc, g, Y, o1, o2, m0 + wm * 64, n0, 0, wn, lane);
-      zero_acc();
-      c_k = 0;
-      ++c_ord;
-    }
-  };
-
-  // prologue: stages 0..2 in flight, stage 0 landed and visible, its fragments in registers
-  issue(0); advance_cursor(); issue(1); advance_cursor(); issue(2); advance_cursor();
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  __syncthreads();
-  CRFrags F0, F1;
-  {
-    float raw[2][8];
-    read_a(0, F0);
-    read_b_raw(0, raw);
-    convert_b(raw, F0);
-  }
-  int nbuf = 1, ibuf = 3;   // ring slots of stage s+1 (read in step s) and of stage s+3 (issued in step s)
-  auto step = [&](const CRFrags& cur, CRFrags& nxt) __attribute__((always_inline)) {
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // this wave's copies of stage s+1 have landed
-    __syncthreads();                                      // ... and everybody's; slot of stage s-1 is free
-    // one basic block: copies of stage s+3, LDS reads of stage s+1, the MFMAs of stage s, the conversion of s+1
-    issue(ibuf);
-    float raw[2][8];
-    read_b_raw(nbuf, raw);
-    read_a(nbuf, nxt);
-    matrix(cur);
-    convert_b(raw, nxt);
-    // keep the conversion in THIS block (the compiler otherwise sinks it behind the tile-end branch, out of the
-    // MFMA shadow): an empty asm that "uses" the converted fragments
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int part = 0; part < 3; ++part) asm volatile("" : "+v"(nxt.b[j][part]));
-    // schedule: LDS reads first, then behind every MFMA one copy instruction (while there are any) and a few
-    // conversion VALU ops, all in the MFMA's 32-cycle shadow
-    __builtin_amdgcn_sched_group_barrier(0x100, 32, 0);
-#pragma unroll
-    for (int q = 0; q < 24; ++q) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-    }
-    tile_end();
-    advance_cursor();
-    nbuf = nbuf == CR_RING - 1 ? 0 : nbuf + 1;
-    ibuf = ibuf == CR_RING - 1 ? 0 : ibuf + 1;
-  };
-  for (int s = 0; s < S; s += 2) {
-    step(F0, F1);
-    step(F1, F0);
-  }
-}
-
-int launch_cr(const pir_gemm_nn_t& g, hipStream_t s) {
-  const int tiles_m = (int)pir_cdiv(g.M, CR_BM), tiles_n = (int)pir_cdiv(g.N, CR_BN);
-  const long total = (long)tiles_m * tiles_n * g.O1 * g.O2;
-  const int grid = total < PIR_NUM_CU ? (int)total : PIR_NUM_CU;
-  hipLaunchKernelGGL(gemm_nn_cr_kernel, dim3(grid), dim3(512), 0, s, g, tiles_m, tiles_n, (int)total);
-  return pir_launch_status();
-}
-
 template <int TM, int TN, int WM, int WN>
 int launch_cfg(const pir_gemm_nn_t& g, hipStream_t s, const X3Conv* conv = nullptr) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -825,6 +384,8 @@ extern "C" int pir_conv3x3_x3(const void* A3, int a3_kp, const float* X, long x_
   PIR_CHECK_ARG(A3 && X && Y && B > 0 && M > 0 && K > 0 && H > 0 && W > 0 && B <= 65535);
   PIR_CHECK_ARG(a3_kp == (int)(pir_cdiv(K, 16) * 16));
   PIR_CHECK_ARG((long)(M > K ? M : K) * H * W < (1L << 28) && 54L * M * a3_kp < (1L << 31));
+  // pixel -> (row, column) uses pir_fastdiv(n, magic_w), exact only while n * W < 2^32 (n < H*W + one tile of slack)
+  PIR_CHECK_ARG(((long)H * W + 256) * W < (1L << 32));
   pir_gemm_nn_t g;
   g.A = nullptr; g.a_s1 = g.a_s2 = 0; g.a_sm = 0; g.a_sk = 0;
   g.X = X; g.x_s1 = x_bs; g.x_s2 = 0; g.ldx = (long)H * W;
@@ -866,39 +427,55 @@ extern "C" int pir_split_bf16x3(const float* W, int M, int K, long sm, long sk, 
 bool pir_nn_x3_wanted(const pir_gemm_nn_t* a, int knob) {
   // measured (bench.py, batch 32): the bf16x3 path is at least as fast as fp32 MFMA for every gemm_nn of the
   // train step, with or without pre-split weights, so it is the default; knob 0 forces the fp32 kernel.
-  (void)a;
+  // The kernel addresses one image of X through a buffer descriptor of ((K-1)*ldx + N)*4 bytes and signed 32-bit
+  // byte offsets (k_padded * ldx * 4): larger operands take the fp32 kernel (element offsets, checked < 2^31).
+  const long kp = pir_cdiv(a->K, 16) * 16;
+  if ((kp * a->ldx + a->N) * 4 >= (1L << 31)) return false;
   return knob != 0;
 }
 
-int pir_nn_x3_launch(const pir_gemm_nn_t* a, int cfg, hipStream_t s) {
+// Tile plan of the bf16x3 kernel for one call: TM*1000 + TN*100 + WM*10 + WN (a workgroup of WM x WN waves, each
+// wave TM x TN MFMA tiles of 32 x 32).  Host-only, also exported (pir_gemm_nn_plan) so tests can pin which
+// instantiation a shape selects.
+int pir_nn_x3_plan(const pir_gemm_nn_t* a, int cfg) {
   const pir_gemm_nn_t& g = *a;
   const int M = g.M;
   const long batch = (long)g.O1 * g.O2;
-  if (cfg == 5 && g.A3) return launch_pp(g, s);
-  if (cfg == 6 && g.A3) return launch_cr(g, s);
   if (cfg >= 0) {
     switch (cfg) {
-      case 0: return launch_cfg<1, 2, 1, 4>(g, s);
-      case 1: return launch_cfg<2, 2, 1, 4>(g, s);
-      case 2: return launch_cfg<3, 2, 1, 4>(g, s);
-      case 3: return launch_cfg<2, 2, 2, 2>(g, s);
-      case 7: return launch_cfg<3, 1, 1, 4>(g, s);   // 96 x 128
-      default: return launch_cfg<1, 2, 2, 2>(g, s);
+      case 0: return 1214;
+      case 1: return 2214;
+      case 2: return 3214;
+      case 3: return 2222;
+      case 7: return 3114;   // 96 x 128
+      default: return 1222;
     }
   }
   // tile choice from the sweep in tools/ktune.py (PIR_X3=1): the 96 x 256 tile (1 KB contiguous per
   // row and stage) wins at the high-resolution levels even with up to ~13 % more padded rows.
-  if (M <= 32) return launch_cfg<1, 2, 1, 4>(g, s);
-  if (M <= 64) return g.K <= 64 ? launch_cfg<1, 2, 2, 2>(g, s) : launch_cfg<2, 2, 1, 4>(g, s);
+  if (M <= 32) return 1214;
+  if (M <= 64) return g.K <= 64 ? 1222 : 2214;
   // 96 x 128 (three workgroups per CU) for the GDFN project_in pair at the 96-channel levels: -6 ... -11 % there,
   // neutral or worse for the other full-resolution shapes (tools/cfg7.py)
   if (g.A3 && ((M >= 384 && g.K <= 128 && g.N >= 4096) || (g.K >= 384 && M == 96 && g.N >= 16384)) &&
       pir_cdiv(M, 96) * 96 * 100 <= pir_cdiv(M, 128) * 128 * 113)
-    return launch_cfg<3, 1, 1, 4>(g, s);
+    return 3114;
   const long pad96 = pir_cdiv(M, 96) * 96, pad128 = pir_cdiv(M, 128) * 128;
   const bool use96 = g.N >= 1024 ? pad96 * 100 <= pad128 * 113 : pad96 < pad128;
   const long blocks = use96 ? pir_cdiv(M, 96) * pir_cdiv(g.N, 256) * batch : pir_cdiv(M, 128) * pir_cdiv(g.N, 128) * batch;
-  if (blocks < 2L * PIR_NUM_CU && pir_cdiv(M, 64) * 64 <= pad128) return launch_cfg<1, 2, 2, 2>(g, s);
-  if (use96) return launch_cfg<3, 2, 1, 4>(g, s);
-  return launch_cfg<2, 2, 2, 2>(g, s);
+  if (blocks < 2L * PIR_NUM_CU && pir_cdiv(M, 64) * 64 <= pad128) return 1222;
+  if (use96) return 3214;
+  return 2222;
+}
+
+int pir_nn_x3_launch(const pir_gemm_nn_t* a, int cfg, hipStream_t s) {
+  const pir_gemm_nn_t& g = *a;
+  switch (pir_nn_x3_plan(a, cfg)) {
+    case 1214: return launch_cfg<1, 2, 1, 4>(g, s);
+    case 2214: return launch_cfg<2, 2, 1, 4>(g, s);
+    case 3214: return launch_cfg<3, 2, 1, 4>(g, s);
+    case 2222: return launch_cfg<2, 2, 2, 2>(g, s);
+    case 3114: return launch_cfg<3, 1, 1, 4>(g, s);
+    default: return launch_cfg<1, 2, 2, 2>(g, s);
+  }
 }

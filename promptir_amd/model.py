@@ -26,16 +26,25 @@ def _check_channels(x: torch.Tensor, expected: int, who: str) -> None:
 
 
 class _ConvParams(nn.Module):
-    """Bias-free convolution weight holder with nn.Conv2d's parameter name, shape and default init."""
+    """Convolution parameter holder with nn.Conv2d's parameter names, shapes, registration order and default init.
+    `bias=True` (never used by the reference's callers, net/model.py:253, train.py:31) adds the bias with its own
+    in-place kernel after the bias-free convolution kernel (ops.BiasAddFn)."""
 
     def __init__(self, in_channels: int, out_channels: int, kernel_size: int, groups: int = 1, bias: bool = False):
         super().__init__()
-        if bias:
-            raise NotImplementedError("bias=True is not built: every caller of the reference uses bias=False "
-                                      "(net/model.py:253, train.py:31)")
         self.in_channels, self.out_channels, self.kernel_size, self.groups = in_channels, out_channels, kernel_size, groups
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, kernel_size, kernel_size))
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))  # nn.Conv2d.reset_parameters
+        if bias:
+            fan_in = (in_channels // groups) * kernel_size * kernel_size
+            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+            self.bias = nn.Parameter(torch.empty(out_channels))
+            nn.init.uniform_(self.bias, -bound, bound)
+        else:
+            self.register_parameter("bias", None)
+
+    def _add_bias(self, y):
+        return y if self.bias is None else ops.BiasAddFn.apply(y, self.bias)
 
 
 class Conv1x1(_ConvParams):
@@ -46,7 +55,7 @@ class Conv1x1(_ConvParams):
 
     def forward(self, x, residual: Optional[torch.Tensor] = None):
         _check_channels(x, self.in_channels, "Conv1x1")
-        return ops.Conv1x1Fn.apply(x, self.weight, residual)
+        return self._add_bias(ops.Conv1x1Fn.apply(x, self.weight, residual))
 
 
 class Conv3x3(_ConvParams):
@@ -57,7 +66,7 @@ class Conv3x3(_ConvParams):
 
     def forward(self, x, residual: Optional[torch.Tensor] = None):
         _check_channels(x, self.in_channels, "Conv3x3")
-        return ops.Conv3x3Fn.apply(x, self.weight, residual)
+        return self._add_bias(ops.Conv3x3Fn.apply(x, self.weight, residual))
 
 
 class DepthwiseConv3x3(_ConvParams):
@@ -68,7 +77,7 @@ class DepthwiseConv3x3(_ConvParams):
 
     def forward(self, x):
         _check_channels(x, self.in_channels, "DepthwiseConv3x3")
-        return ops.DwConvFn.apply(x, self.weight)
+        return self._add_bias(ops.DwConvFn.apply(x, self.weight))
 
 
 class PixelUnshuffle2(nn.Module):
@@ -132,7 +141,10 @@ class FeedForward(nn.Module):
 
     def forward(self, x, residual: Optional[torch.Tensor] = None):
         x = self.project_in(x)
-        x = ops.DwConvGateFn.apply(x, self.dwconv.weight)   # dwconv + chunk + gelu(x1)*x2 fused
+        if self.dwconv.bias is None:
+            x = ops.DwConvGateFn.apply(x, self.dwconv.weight)   # dwconv + chunk + gelu(x1)*x2 fused
+        else:                                                   # the bias sits between the stencil and the gate
+            x = ops.GeluGateFn.apply(self.dwconv(x))
         return self.project_out(x, residual)
 
 
@@ -188,6 +200,9 @@ class TransformerBlock(nn.Module):
     def forward(self, x):
         _check_channels(x, self.norm1.body.normalized_shape[0], "TransformerBlock")
         a, f = self.attn, self.ffn
+        if a.qkv.bias is not None:   # bias=True: composed from the per-op nodes (each conv followed by its bias add)
+            x = a(self.norm1(x), residual=x)
+            return f(self.norm2(x), residual=x)
         # one autograd node per block; residual adds live in the project_out epilogues (forward) and in
         # the LayerNorm-backward kernel (backward).  Equivalent to
         #   x = self.attn(self.norm1(x), residual=x); x = self.ffn(self.norm2(x), residual=x)

@@ -242,6 +242,19 @@ def refresh_split_weights() -> None:
         _refresh_split_batch()
 
 
+def split_weights_signature():
+    """Cheap fingerprint of everything the cached bf16x3 pieces depend on: the raw-pointer generation
+    (`weights_changed`) plus address and torch version counter of every registered weight (load_state_dict,
+    torch optimisers, dist.broadcast into a flat buffer all bump the counter).  Graph-replaying callers compare
+    it with the value at their last refresh."""
+    sig = _WEIGHT_GEN[0]
+    for e in _BATCH["entries"]:
+        w = e["w"]()
+        if w is not None:
+            sig = (sig * 1000003 + w.data_ptr() + 7919 * w._version) & 0xFFFFFFFFFFFFFFFF
+    return sig
+
+
 def _split_weight(w: torch.Tensor, dgrad: bool, taps: bool = False):
     """bf16x3 pieces of a 1x1 (taps=False) or dense 3x3 (taps=True) weight in forward / input-gradient orientation.
     The first request for a weight splits it alone and registers it; afterwards a stale entry (optimiser step)
@@ -648,6 +661,59 @@ class DwConvFn(torch.autograd.Function):
         return dx, _ret(dw, ctx.sink)
 
 
+class BiasAddFn(torch.autograd.Function):
+    """y += bias[c] in place on the fresh output of a bias-free convolution kernel (`bias=True`,
+    net/model.py:88-92,111-113,206,294-320); backward: db = sum_{b,h,w} dy."""
+
+    @staticmethod
+    def forward(ctx, y, bias):
+        _require_gpu(y, bias)
+        if _planes(y) is not y:
+            raise RuntimeError("BiasAddFn expects the plane layout of a convolution output")
+        b, c, h, w = y.shape
+        check(lib.pir_bias_add(y.data_ptr(), _bs(y), bias.data_ptr(), b, c, h * w, _stream()), "pir_bias_add")
+        ctx.mark_dirty(y)
+        ctx.sink = _sink(bias)
+        ctx.c = c
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        db = None
+        if ctx.needs_input_grad[1]:
+            dyp = _planes(dy)
+            b, c, h, w = dyp.shape
+            db = ctx.sink if ctx.sink is not None else torch.empty((c,), dtype=torch.float32, device=dy.device)
+            check(lib.pir_bias_grad(dyp.data_ptr(), _bs(dyp), db.data_ptr(), b, c, h * w, _stream()), "pir_bias_grad")
+        return dy, _ret(db, ctx.sink)
+
+
+class GeluGateFn(torch.autograd.Function):
+    """g = gelu(t[:, :hid]) * t[:, hid:] (net/model.py:96-97) as its own node: the biased GDFN adds the depthwise
+    bias between the stencil and the gate, so the fused DwConvGateFn does not apply there."""
+
+    @staticmethod
+    def forward(ctx, t):
+        _require_gpu(t)
+        t = _planes(t)
+        b, c2, h, w = t.shape
+        hid = c2 // 2
+        g = torch.empty((b, hid, h, w), dtype=torch.float32, device=t.device)
+        check(lib.pir_gelu_gate(t.data_ptr(), _bs(t), g.data_ptr(), _bs(g), b, hid, h * w, _stream()), "pir_gelu_gate")
+        ctx.save_for_backward(t)
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        t, = ctx.saved_tensors
+        dg = _planes(dg)
+        b, c2, h, w = t.shape
+        dt = torch.empty((b, c2, h, w), dtype=torch.float32, device=t.device)
+        check(lib.pir_gelu_gate_bwd(t.data_ptr(), _bs(t), dg.data_ptr(), _bs(dg), dt.data_ptr(), _bs(dt), b, c2 // 2, h * w,
+                                    _stream()), "pir_gelu_gate_bwd")
+        return dt
+
+
 class DwConvGateFn(torch.autograd.Function):
     """g = gelu(dw(x)[:hid]) * dw(x)[hid:]; the pre-gate tensor is recomputed in backward."""
 
@@ -682,8 +748,29 @@ class MdtaCoreFn(torch.autograd.Function):
         return dqkv, _ret(dtemp, ctx.sink), None
 
 
-USE_SIDE_STREAM = _os.environ.get("PIR_SIDE_STREAM", "1") != "0"
+USE_SIDE_STREAM = _os.environ.get("PIR_SIDE_STREAM", "1") != "0"   # default for callers outside a trainer
 _SIDE_STREAMS = {}
+_SIDE_OVERRIDE = []   # innermost `side_streams(...)` scope wins over the module default
+
+
+class side_streams:
+    """Scope in which the block backward may (or may not) put its weight-gradient GEMMs on a side stream.
+    Per-caller state (a trainer enters it around its own forward/backward) instead of a process-wide switch."""
+
+    def __init__(self, enabled: bool):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        _SIDE_OVERRIDE.append(self.enabled)
+        return self
+
+    def __exit__(self, *exc):
+        _SIDE_OVERRIDE.pop()
+        return False
+
+
+def _side_stream_enabled() -> bool:
+    return _SIDE_OVERRIDE[-1] if _SIDE_OVERRIDE else USE_SIDE_STREAM
 
 
 class _SideWgrads:
@@ -695,7 +782,7 @@ class _SideWgrads:
     def __init__(self, device):
         self.main = torch.cuda.current_stream(device)
         self.side = None
-        if USE_SIDE_STREAM and lib.records is None:   # the instrumented (timed) step stays on one stream
+        if _side_stream_enabled() and lib.records is None:   # the instrumented (timed) step stays on one stream
             key = (device.index, self.main.cuda_stream)   # one side stream per main stream (two-stream training)
             self.side = _SIDE_STREAMS.get(key)
             if self.side is None:

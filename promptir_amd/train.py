@@ -36,6 +36,19 @@ def warmup_cosine_lr(epoch: int, base_lr: float = 2e-4, warmup_epochs: int = 15,
         1 + math.cos(math.pi * (epoch - warmup_epochs) / (max_epochs - warmup_epochs)))
 
 
+def lightning_epoch_lr(epoch: int, **kw) -> float:
+    """Learning rate the reference actually TRAINS epoch `epoch` with under Lightning 2.0.1.
+
+    `lr_scheduler_step` (train.py:48-50) calls `scheduler.step(self.current_epoch)`.  Lightning's
+    `FitLoop.on_advance_end` runs `update_lr_schedulers("epoch", ...)` at the END of epoch N, before
+    `epoch_progress.increment_completed()`, and `trainer.current_epoch` is `epoch_progress.current.completed`: the
+    call made at the end of epoch N passes N, so epoch N+1 trains with closed_form(N); epoch 0 trains with the
+    scheduler's construction-time value closed_form(0) = warmup_start_lr = 0.  Epochs 0 and 1 therefore both run
+    with lr 0.  (Lightning is not installed in the build container; this ordering is restated from the 2.0.1
+    sources as recorded in ADVICE round 1 and is not executed anywhere here.)"""
+    return warmup_cosine_lr(max(epoch - 1, 0), **kw)
+
+
 def live_parameters(net: nn.Module, unused_prefixes: Iterable[str] = UNUSED_PREFIXES):
     pref = tuple(unused_prefixes)
     return [(n, p) for n, p in net.named_parameters() if not n.startswith(pref)]
@@ -87,10 +100,61 @@ class FlatAdamW:
             raise RuntimeError("FlatAdamW.step: the AdamW kernel is HIP-only (no CPU fallback)")
 
     def state_dict(self):
+        """Flat layout (this repo's own, compact)."""
         return {"steps": self.steps, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
                 "offsets": dict(self.offsets)}
 
-    def load_state_dict(self, sd):
+    def torch_state_dict(self, net: nn.Module, lr: Optional[float] = None) -> dict:
+        """The same state in torch.optim.AdamW.state_dict() layout, as Lightning stores it in
+        `checkpoint["optimizer_states"][0]` for the reference's `optim.AdamW(self.parameters(), lr=2e-4)`
+        (train.py:53): parameter indices count ALL parameters in `net.parameters()` order; the six parameters that
+        never receive a gradient have no state entry (torch creates state lazily, on the first step with a grad)."""
+        state = {}
+        names = [n for n, _ in net.named_parameters()]
+        for i, n in enumerate(names):
+            if n not in self.offsets or self.steps == 0:
+                continue
+            o, k = self.offsets[n], dict(self.named)[n].numel()
+            shape = dict(self.named)[n].shape
+            state[i] = {"step": torch.tensor(float(self.steps)),
+                        "exp_avg": self.exp_avg[o:o + k].view(shape).detach().clone(),
+                        "exp_avg_sq": self.exp_avg_sq[o:o + k].view(shape).detach().clone()}
+        group = {"lr": self.lr if lr is None else lr, "betas": tuple(self.betas), "eps": self.eps,
+                 "weight_decay": self.weight_decay, "amsgrad": False, "maximize": False, "foreach": None,
+                 "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd, net: Optional[nn.Module] = None):
+        """Accepts the flat layout or a torch.optim.AdamW state_dict (a reference / Lightning checkpoint); the
+        latter needs `net` to map parameter indices to names."""
+        if "state" in sd and "param_groups" in sd:
+            if net is None:
+                raise ValueError("a torch-layout optimizer state needs the module to map parameter indices")
+            names = [n for n, _ in net.named_parameters()]
+            order = []
+            for g in sd["param_groups"]:
+                order += list(g["params"])
+            if len(order) != len(names):
+                raise ValueError(f"optimizer state has {len(order)} parameters, the module {len(names)}")
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
+            steps = set()
+            shapes = {n: p for n, p in self.named}
+            for pos, idx in enumerate(order):
+                st = sd["state"].get(idx)
+                n = names[pos]
+                if st is None:
+                    continue
+                if n not in self.offsets:
+                    raise ValueError(f"optimizer state for {n}, which this engine never updates")
+                o, k = self.offsets[n], shapes[n].numel()
+                self.exp_avg[o:o + k].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(st["step"])))
+            if len(steps) > 1:
+                raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): not a plain AdamW run")
+            self.steps = steps.pop() if steps else 0
+            return
         self.steps = int(sd["steps"])
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
@@ -99,9 +163,13 @@ class FlatAdamW:
 def allreduce_mean_(flat_grad: torch.Tensor, world_size: int) -> float:
     """One SUM all-reduce over the whole flat gradient (RCCL on GPUs, gloo on CPU tests).
     Returns the scale (1/world) the optimiser kernel folds into its gradient read."""
-    if world_size > 1:
+    if dist.is_initialized():   # also in a 1-rank group (PIR_FORCE_PG=1): the collective path is then exercised on one GPU
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return 1.0 / world_size
+
+
+class _CaptureRefused(RuntimeError):
+    """The HIP runtime would not capture / instantiate the step as a graph (as opposed to the step itself failing)."""
 
 
 class DataParallelTrainer:
@@ -113,7 +181,7 @@ class DataParallelTrainer:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.opt = FlatAdamW(net, lr=lr)
-        if self.world > 1:  # DDP's initial parameter broadcast from rank 0
+        if dist.is_initialized():  # DDP's initial parameter broadcast from rank 0 (a 1-rank group runs it too)
             dist.broadcast(self.opt.param, src=0)
         if loss_fn is None:
             from .ops import l1_loss as loss_fn
@@ -130,10 +198,8 @@ class DataParallelTrainer:
         if micro_streams is None:   # part streams only pay inside the graph (eagerly the extra launches bind the CPU)
             micro_streams = int(os.environ.get("PIR_MICRO_STREAMS", "4" if self.graph else "1"))
         self.micro_streams = max(1, micro_streams) if self.opt.param.is_cuda else 1
+        self._split_sig = None
         if self.micro_streams > 1:
-            from . import ops
-
-            ops.USE_SIDE_STREAM = False   # the parts already overlap; side streams inside them do not mix with capture
             dev = self.opt.param.device
             n = self.micro_streams
             self._streams = [torch.cuda.Stream(dev) for _ in range(n)]
@@ -155,6 +221,16 @@ class DataParallelTrainer:
 
     def _fwd_bwd(self, degrad_patch: torch.Tensor, clean_patch: torch.Tensor, two_streams: bool = True) -> torch.Tensor:
         """forward + L1 + backward; leaves the batch-mean gradient in opt.grad and returns the loss (device scalar)."""
+        if not degrad_patch.is_cuda:
+            return self._fwd_bwd_parts(degrad_patch, clean_patch, two_streams)
+        from . import ops
+
+        # the part streams already overlap; side streams inside them do not mix with capture (per-trainer choice,
+        # scoped to this trainer's own forward/backward)
+        with ops.side_streams(self.micro_streams == 1 and ops.USE_SIDE_STREAM):
+            return self._fwd_bwd_parts(degrad_patch, clean_patch, two_streams)
+
+    def _fwd_bwd_parts(self, degrad_patch: torch.Tensor, clean_patch: torch.Tensor, two_streams: bool) -> torch.Tensor:
         b = degrad_patch.shape[0]
         n = min(self.micro_streams, max(1, b // 4))      # parts of at least four samples
         if not (two_streams and n > 1):
@@ -197,14 +273,27 @@ class DataParallelTrainer:
         self._sx, self._st = degrad_patch.clone(), clean_patch.clone()
         side = torch.cuda.Stream(degrad_patch.device)
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                # warm-up on a side stream: caches, workspaces, allocator pools
+        # Warm-up OUTSIDE any error handling: argument-check, workspace, out-of-memory or asynchronous HIP errors
+        # of the step itself are defects and must propagate.
+        with torch.cuda.stream(side):                # on a side stream: caches, workspaces, allocator pools
             for _ in range(2):
                 self._fwd_bwd(self._sx, self._st)
         torch.cuda.current_stream().wait_stream(side)
-        self._graph = torch.cuda.CUDAGraph()
-        # thread_local: the RCCL watchdog thread of a multi-GPU job may query its events while this thread captures
-        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
-            self._sloss = self._fwd_bwd(self._sx, self._st)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        try:
+            # thread_local: the RCCL watchdog thread of a multi-GPU job may query its events while this thread captures
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                sloss = self._fwd_bwd(self._sx, self._st)
+        except RuntimeError as exc:
+            # Only a capture-specific refusal (the runtime cannot capture / instantiate this stream work) falls back;
+            # anything else is re-raised.  torch.cuda.graph.__exit__ has already ended the capture on every stream
+            # that joined it.
+            msg = str(exc).lower()
+            if not any(k in msg for k in ("captur", "graph")):
+                raise
+            raise _CaptureRefused(str(exc)) from exc
+        self._graph, self._sloss = graph, sloss
         self._graph_shape = tuple(degrad_patch.shape)
 
     def _ensure_graph(self, degrad_patch: torch.Tensor, clean_patch: torch.Tensor) -> None:
@@ -212,10 +301,10 @@ class DataParallelTrainer:
             return
         try:
             self._capture(degrad_patch, clean_patch)
-        except Exception as exc:   # e.g. a runtime that refuses the capture: keep training, eagerly on one stream
+        except _CaptureRefused as exc:   # keep training, eagerly on one stream
             import warnings
 
-            warnings.warn(f"hipGraph capture failed ({exc!r}); falling back to the eager single-stream step")
+            warnings.warn(f"hipGraph capture refused ({exc}); falling back to the eager single-stream step")
             torch.cuda.synchronize()
             self.graph, self._graph, self.micro_streams = False, None, 1
             self._use_sinks_default()
@@ -225,30 +314,63 @@ class DataParallelTrainer:
         if self.graph and degrad_patch.is_cuda:
             self._ensure_graph(degrad_patch, clean_patch)
 
-    def train_step(self, degrad_patch: torch.Tensor, clean_patch: torch.Tensor, lr: Optional[float] = None):
-        """reference train.py:37-46 (+ optimizer.step of Lightning's loop)."""
+    def forward_backward(self, degrad_patch: torch.Tensor, clean_patch: torch.Tensor) -> torch.Tensor:
+        """forward + L1 + backward of one batch (reference train.py:37-46 + Lightning's loss.backward()): leaves the
+        local batch-mean gradient in the flat buffer `opt.grad` and returns the loss (device scalar).  hipGraph
+        replay when enabled, eager launches otherwise."""
+        if not degrad_patch.is_cuda:
+            return self._fwd_bwd(degrad_patch, clean_patch)
         from . import ops
 
-        if self.graph and degrad_patch.is_cuda and ops.lib.records is None:
+        if self.graph and ops.lib.records is None:
             self._ensure_graph(degrad_patch, clean_patch)
-        if self.graph and degrad_patch.is_cuda and ops.lib.records is None:
+        if self.graph and ops.lib.records is None:
+            # No Python runs inside a replay, so `_split_weight`'s version check cannot: if any weight changed since
+            # the pieces were last refreshed (load_state_dict, a checkpoint, dist.broadcast, an external optimiser),
+            # re-split them all now (one launch).
+            sig = ops.split_weights_signature()
+            if sig != self._split_sig:
+                ops.refresh_split_weights()
+                self._split_sig = ops.split_weights_signature()
             self._sx.copy_(degrad_patch)
             self._st.copy_(clean_patch)
             self._graph.replay()
-            loss = self._sloss.clone()
-        else:   # eager; the instrumented (per-kernel timed) step stays on one stream
-            loss = self._fwd_bwd(degrad_patch, clean_patch, two_streams=ops.lib.records is None)
+            return self._sloss.clone()
+        # eager; the instrumented (per-kernel timed) step stays on one stream
+        return self._fwd_bwd(degrad_patch, clean_patch, two_streams=ops.lib.records is None)
+
+    def train_step(self, degrad_patch: torch.Tensor, clean_patch: torch.Tensor, lr: Optional[float] = None):
+        """reference train.py:37-46 (+ optimizer.step of Lightning's loop)."""
+        loss = self.forward_backward(degrad_patch, clean_patch)
         scale = allreduce_mean_(self.opt.grad, self.world)
         self.opt.step(lr=lr, grad_scale=scale)
-        if self.graph:
+        if self.graph and self.opt.param.is_cuda:
+            from . import ops
+
             ops.refresh_split_weights()
+            self._split_sig = ops.split_weights_signature()
         return loss
 
-    def checkpoint(self, epoch: int) -> dict:
-        """Lightning-compatible dict: state_dict keys are `net.<PromptIR key>`."""
-        return {"epoch": epoch, "global_step": self.opt.steps,
+    def checkpoint(self, epoch: int, lr: Optional[float] = None) -> dict:
+        """A dict in the layout Lightning 2.0.1 writes for the reference's PromptIRModel (train.py:28-56, :334):
+        `state_dict` keys are `net.<PromptIR key>`, `optimizer_states[0]` is a torch.optim.AdamW state_dict,
+        `lr_schedulers[0]` the LinearWarmupCosineAnnealingLR state, plus the version / loops / callbacks keys
+        `load_from_checkpoint` and `trainer.fit(ckpt_path=...)` look up (loop progress is not tracked here: `loops`
+        and `callbacks` are empty, so Lightning restarts its counters from `epoch` / `global_step`)."""
+        cur_lr = self.opt.lr if lr is None else lr
+        sched = {"warmup_epochs": 15, "max_epochs": 150, "warmup_start_lr": 0.0, "eta_min": 0.0,
+                 "base_lrs": [self.opt.lr], "last_epoch": epoch, "_step_count": epoch + 2, "verbose": False,
+                 "_get_lr_called_within_step": False, "_last_lr": [cur_lr]}
+        return {"epoch": epoch, "global_step": self.opt.steps, "pytorch-lightning_version": "2.0.1",
                 "state_dict": {"net." + k: v.detach().clone() for k, v in self.net.state_dict().items()},
-                "optimizer_states": [self.opt.state_dict()]}
+                "loops": {}, "callbacks": {}, "hparams_name": None, "hyper_parameters": {},
+                "optimizer_states": [self.opt.torch_state_dict(self.net, cur_lr)], "lr_schedulers": [sched]}
+
+
+def load_checkpoint_file(path: str) -> dict:
+    """torch.load for trusted Lightning checkpoints (they hold non-tensor payload the `weights_only` default of recent
+    torch releases rejects)."""
+    return torch.load(path, map_location="cpu", weights_only=False)
 
 
 def load_lightning_checkpoint(net: nn.Module, ckpt: dict) -> None:

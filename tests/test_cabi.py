@@ -34,6 +34,34 @@ def test_host_side_argument_checks_need_no_gpu():
     assert _lib.lib.pir_gemm_nt_ws_floats(48, 48, 16384, 8, 1) > 0
     g = _lib.GemmNN()
     assert _lib.lib.pir_gemm_nn(ctypes.byref(g), None) == -22
+    assert _lib.lib.pir_bias_add(None, 0, None, 1, 1, 1, None) == -22
+
+
+def test_fastdiv_bounds_and_conv3x3_guard():
+    """pir_fastdiv(n, magic(d)) = umulhi(n, floor(2^32/d) + 1) is exact only while n * d < 2^32 (pir_common.h).
+    The bf16x3 dense-3x3 kernel divides pixel indices by the image width: images where that bound does not hold
+    (W=2048, H>1024, first wrong quotient at n=2099199) must be refused, not mis-computed."""
+    import numpy as np
+
+    from promptir_amd import _lib
+
+    def magic(d):
+        return 0 if d <= 1 else (1 << 32) // d + 1
+
+    def fastdiv(n, m):
+        return (n.astype(np.uint64) * np.uint64(m)) >> np.uint64(32) if m else n
+
+    for d in (3, 7, 48, 127, 128, 255, 510, 1021, 2048):
+        top = (1 << 32) // d
+        n = np.unique(np.concatenate([np.arange(0, min(top, 1 << 16)), np.arange(max(top - 4096, 0), top),
+                                      (np.arange(1, 4097) * d - 1).clip(0, top - 1), np.arange(1, 4097) * d % top]))
+        assert np.array_equal(fastdiv(n, magic(d)), n // d), d
+    n = np.array([2099199], dtype=np.int64)          # row 1024, column 2047 of a 2048-wide image
+    assert int(fastdiv(n, magic(2048))[0]) != 2099199 // 2048
+    # host-side guard: rejected before any launch (dummy non-null pointers are never dereferenced)
+    fake = ctypes.c_void_p(256)
+    assert _lib.lib.pir_conv3x3_x3(fake, 16, fake, 3 * 2048 * 1100, fake, 48 * 2048 * 1100, None, 0,
+                                   1, 48, 3, 1100, 2048, None) == -22
 
 
 def test_module_has_no_cpu_fallback():
@@ -58,3 +86,86 @@ def test_state_dict_matches_reference_layout():
     assert list(sd.keys()) == list(ref["shapes"].keys())
     assert all(list(sd[k].shape) == ref["shapes"][k] for k in sd)
     assert sum(p.numel() for p in net.parameters()) == ref["num_params"] == 35_592_263
+    # bias=True (net/model.py:253): same registration order as nn.Conv2d (weight, bias)
+    refb = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_shapes_bias.json")))
+    netb = PromptIR(decoder=True, bias=True)
+    assert list(netb.state_dict().keys()) == refb["keys"]
+    assert sum(p.numel() for p in netb.parameters()) == refb["num_params"]
+
+
+def test_checkpoint_interchange_with_the_lightning_layout():
+    """a reference / Lightning checkpoint stores a torch.optim.AdamW state_dict under
+    `optimizer_states[0]`; resuming from one must work, and the checkpoints written here must load into a real
+    torch.optim.AdamW over the module's parameters (what Lightning does on `fit(ckpt_path=...)`)."""
+    import torch
+
+    from net.model import PromptIR
+    from promptir_amd.train import DataParallelTrainer, FlatAdamW, load_lightning_checkpoint
+
+    kw = dict(decoder=True, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1)
+    torch.manual_seed(0)
+    ref_net = PromptIR(**kw)
+    # a reference-layout checkpoint: AdamW over ALL parameters, state only for those that received gradients
+    params = list(ref_net.parameters())
+    names = [n for n, _ in ref_net.named_parameters()]
+    opt = torch.optim.AdamW(params, lr=2e-4)
+    for n, p in zip(names, params):
+        if not n.startswith(("chnl_reduce", "reduce_noise_channel_")):
+            p.grad = torch.randn_like(p) * 1e-3
+    opt.step(); opt.step()
+    ckpt = {"epoch": 3, "global_step": 2, "pytorch-lightning_version": "2.0.1",
+            "state_dict": {"net." + k: v.clone() for k, v in ref_net.state_dict().items()},
+            "optimizer_states": [opt.state_dict()], "lr_schedulers": [{}], "loops": {}, "callbacks": {}}
+
+    net = PromptIR(**kw)
+    load_lightning_checkpoint(net, ckpt)
+    flat = FlatAdamW(net)
+    flat.load_state_dict(ckpt["optimizer_states"][0], net)
+    assert flat.steps == 2
+    sd = opt.state_dict()["state"]
+    for i, n in enumerate(names):
+        if i in sd:
+            o, k = flat.offsets[n], params[i].numel()
+            assert torch.equal(flat.exp_avg[o:o + k], sd[i]["exp_avg"].reshape(-1)), n
+            assert torch.equal(flat.exp_avg_sq[o:o + k], sd[i]["exp_avg_sq"].reshape(-1)), n
+        else:
+            assert n not in flat.offsets
+    # and back: what this repo writes loads into torch's AdamW
+    trainer = DataParallelTrainer.__new__(DataParallelTrainer)
+    trainer.net, trainer.opt = net, flat
+    out = trainer.checkpoint(epoch=3, lr=1e-4)
+    assert out["pytorch-lightning_version"] == "2.0.1" and "loops" in out and "callbacks" in out and "lr_schedulers" in out
+    assert list(out["state_dict"].keys()) == ["net." + k for k in ref_net.state_dict().keys()]
+    opt2 = torch.optim.AdamW(list(PromptIR(**kw).parameters()), lr=2e-4)
+    opt2.load_state_dict(out["optimizer_states"][0])
+    st2 = opt2.state_dict()["state"]
+    assert set(st2.keys()) == set(sd.keys())
+    for i in sd:
+        assert torch.equal(st2[i]["exp_avg"], sd[i]["exp_avg"]) and float(st2[i]["step"]) == 2.0
+    assert opt2.state_dict()["param_groups"][0]["lr"] == 1e-4
+
+
+
+def test_gemm_plan_reaches_the_tuned_tiles_for_config3_shapes():
+    """BASELINE config 3 (128x128 patches): the GDFN project_in pair of the 96-channel levels (dec1 / refinement) was
+    tuned onto the 96 x 128 tile (gemm_x3.hip, pir_nn_x3_plan).  Pin that those exact shapes select it; the GPU
+    parity of the same shapes is tests/test_kernels_gpu.py::test_conv1x1_config3_shapes."""
+    from promptir_amd import _lib
+
+    def plan(M, K, N, batch, presplit=True):
+        g = _lib.GemmNN()
+        g.M, g.K, g.N, g.O1, g.O2, g.ldx, g.ldy = M, K, N, batch, 1, N, N
+        g.A3 = 256 if presplit else None
+        return _lib.lib.pir_gemm_nn_plan(ctypes.byref(g))
+
+    assert plan(510, 96, 16384, 32) == 3114      # project_in forward, dec1 / refinement
+    assert plan(96, 510, 16384, 32) == 3114      # its input gradient (M = 96, K = 510, N = 16384)
+    assert plan(510, 96, 4096, 32) == 3114       # level 2 forward
+    assert plan(96, 510, 16384, 2) == 3114       # the test-sized batch takes the same branch
+    assert plan(288, 96, 16384, 32) == 3214      # qkv: 96 x 256
+    assert plan(48, 48, 16384, 32) == 1222
+    assert plan(48, 144, 16384, 32) == 2214
+    assert plan(96, 510, 16384, 32, presplit=False) != 3114   # the branch needs pre-split weights
+    assert plan(0, 1, 1, 1) == -22
+    # operands beyond the 32-bit byte offsets of the bf16x3 kernel fall back to the fp32 kernel (ADVICE round 1)
+    assert plan(96, 255, 2200 * 2048, 1) == 0

@@ -56,3 +56,36 @@ def test_evaluate_cli_synthetic():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("Denoise sigma=")]
     assert len(lines) == 3 and all("psnr:" in l for l in lines)
+
+
+def _run(cmd, env_extra, timeout=900):
+    env = dict(os.environ, **env_extra)
+    return subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=timeout, env=env)
+
+
+def test_bench_runs_under_an_rccl_process_group():
+    """The N>1 code path on the one GPU there is: `PIR_FORCE_PG=1` makes a world-size-1 job initialise the RCCL
+    (`nccl`) process group, broadcast the flat parameters, capture the hipGraph beside the RCCL watchdog thread,
+    all-reduce the flat gradient over RCCL every step, and destroy the group (reference train.py:336-341: DDP over
+    NCCL).  Runs in a fresh child process."""
+    import json
+
+    out = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                "--batch", "8", "--no-cpu-baseline"],
+               {"PIR_FORCE_PG": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533", "RANK": "0", "WORLD_SIZE": "1",
+                "LOCAL_RANK": "0"})
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 1 and rec["config"]["process_group"] == "nccl"
+    assert rec["config"]["execution"].startswith("hipGraph=1")
+    assert rec["config"]["step1_loss_check"]["ok"] is True
+
+
+def test_train_cli_under_an_rccl_process_group(tmp_path):
+    out = _run([sys.executable, os.path.join(ROOT, "train.py"), "--epochs", "3", "--batch_size", "4", "--synthetic", "8",
+                "--patch_size", "64", "--ckpt_dir", str(tmp_path / "ck"), "--start_epoch", "2", "--max_steps", "2"],
+               {"PIR_FORCE_PG": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29534", "RANK": "0", "WORLD_SIZE": "1",
+                "LOCAL_RANK": "0"})
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "process group nccl" in out.stdout

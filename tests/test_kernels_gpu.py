@@ -41,6 +41,59 @@ def test_conv1x1_fwd_bwd(b, cin, cout, h, w):
     close(dw, wr.grad, rtol=5e-5)
 
 
+@pytest.mark.parametrize("cin,cout", [(96, 510), (96, 288), (255, 96), (48, 254)])
+def test_conv1x1_config3_shapes(cin, cout):
+    """The 1x1 convolutions at BASELINE config 3's full resolution (N = 128*128 = 16384 pixels per image): forward,
+    input gradient and weight gradient vs PyTorch CPU.  (96, 510) is the dec1 / refinement project_in pair whose
+    forward (M=510, K=96) and input gradient (M=96, K=510) run on the 96 x 128 tile, `launch_cfg<3,1,1,4>`
+    (pinned by tests/test_cabi.py::test_gemm_plan_reaches_the_tuned_tiles_for_config3_shapes)."""
+    import ctypes
+
+    from promptir_amd import _lib, ops
+
+    b, h, w = 2, 128, 128
+    x, wt, dy = rnd("x", b, cin, h, w), rnd("w", cout, cin, 1, 1), rnd("dy", b, cout, h, w)
+    xd, wd, dyd = x.to(DEV), wt.to(DEV), dy.to(DEV)
+    if (cin, cout) == (96, 510):
+        for M, K, dgrad in ((cout, cin, False), (cin, cout, True)):
+            a3, kp = ops._split_weight(wd, dgrad=dgrad)
+            g = _lib.GemmNN()
+            g.M, g.K, g.N, g.O1, g.O2, g.ldx, g.ldy, g.A3 = M, K, h * w, b, 1, h * w, h * w, a3.data_ptr()
+            assert _lib.lib.pir_gemm_nn_plan(ctypes.byref(g)) == 3114
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    y = F.conv2d(xr, wr)
+    y.backward(dy)
+    close(ops.conv1x1_forward(xd, wd), y.detach())
+    close(ops.conv1x1_dgrad(dyd, wd), xr.grad)
+    close(ops.conv1x1_wgrad(dyd, xd, wd), wr.grad, rtol=5e-5)
+
+
+def test_bias_and_gate_kernels():
+    """bias=True pieces (bias.hip) vs PyTorch CPU on ragged planes."""
+    from promptir_amd import ops
+
+    for (b, c, h, w) in ((2, 5, 9, 11), (1, 254, 16, 16), (3, 2, 128, 128)):
+        y, bias, dy = rnd("y", b, c, h, w), rnd("bias", c), rnd("dy", b, c, h, w)
+        yd = y.to(DEV).requires_grad_(True)
+        bd = bias.to(DEV).requires_grad_(True)
+        src = ops.CatChannelsFn.apply(yd[:, :1], yd[:, 1:])   # a fresh non-leaf tensor produced by a HIP op
+        out = ops.BiasAddFn.apply(src, bd)
+        out.backward(dy.to(DEV))
+        close(out.detach(), y + bias.view(1, -1, 1, 1))
+        close(bd.grad, dy.sum(dim=(0, 2, 3)), rtol=5e-5)
+        close(yd.grad, dy)
+    for (b, hid, h, w) in ((2, 5, 9, 11), (1, 127, 16, 16)):
+        t, dg = rnd("t", b, 2 * hid, h, w) * 3, rnd("dg", b, hid, h, w)
+        tr = t.clone().requires_grad_(True)
+        g = F.gelu(tr[:, :hid]) * tr[:, hid:]
+        g.backward(dg)
+        td = t.to(DEV).requires_grad_(True)
+        gd = ops.GeluGateFn.apply(td)
+        gd.backward(dg.to(DEV))
+        close(gd.detach(), g.detach())
+        close(td.grad, tr.grad)
+
+
 def test_conv1x1_channel_slices():
     """Operands that are channel slices of larger buffers (free batch stride)."""
     from promptir_amd import ops

@@ -27,7 +27,11 @@ def _net(ctor, seed, dev):
 
 
 CASES = [("model_small_64.npz", True), ("model_small_72x88.npz", True), ("model_small_128.npz", False),
-         ("model_full_64.npz", True), ("model_full_128.npz", False)]
+         ("model_full_64.npz", True), ("model_full_128.npz", False),
+         # BASELINE config 3 shapes: full depth, 128x128, WITH backward (every N = 16384 gradient GEMM, every
+         # split-K plan of the 128^2 levels)
+         ("model_full_128_bwd.npz", True),
+         ("model_small_64_bias.npz", True)]   # bias=True (net/model.py:253)
 
 
 @pytest.mark.parametrize("fname,backward", CASES)

@@ -23,14 +23,15 @@ def _build(tag):
 
     parts = tag.split("_")
     kind = parts[0]
+    bias = tag.endswith("_bias")
     if kind == "attn":
-        return M.Attention(int(parts[1]), int(parts[2]), False)
+        return M.Attention(int(parts[1]), int(parts[2]), bias)
     if kind == "ffn":
-        return M.FeedForward(int(parts[1]), 2.66, False)
+        return M.FeedForward(int(parts[1]), 2.66, bias)
     if kind == "ln":
         return M.LayerNorm(48, "WithBias" if parts[1] == "withbias" else "BiasFree")
     if kind == "tblock":
-        return M.TransformerBlock(int(parts[1]), int(parts[2]), 2.66, False,
+        return M.TransformerBlock(int(parts[1]), int(parts[2]), 2.66, bias,
                                   "BiasFree" if tag.endswith("biasfree") else "WithBias")
     if kind == "down":
         return M.Downsample(48)
@@ -48,16 +49,19 @@ def _build(tag):
 
 
 def _tags():
-    z = util.load_npz("modules.npz")
-    return sorted({k.split("/")[0] for k in z.files})
+    out = []
+    for f in ("modules.npz", "modules_bias.npz"):   # bias=True modules: net/model.py:88-92,111-113
+        z = util.load_npz(f)
+        out += sorted({k.split("/")[0] for k in z.files})
+    return out
 
 
 @pytest.mark.parametrize("tag", _tags())
 def test_module_parity(tag):
-    from tests.test_oracle_golden import _run_module
+    from tests.test_oracle_golden import _module_file, _run_module
 
     dev = torch.device("cuda:0")
-    z = util.load_npz("modules.npz")
+    z = util.load_npz(_module_file(tag))
     shapes = {k: tuple(v) for k, v in json.loads(str(z[f"{tag}/param_shapes"])).items()}
     y_ref = z[f"{tag}/y"]
     x_cpu, dy_cpu = util.module_inputs(tag, z[f"{tag}/x_shape"], y_ref.shape)

@@ -42,7 +42,8 @@ def _check_grads(z, prefix, named_grads, rtol=2e-4):
 
 
 MODEL_CASES = [("model_small_64.npz", True), ("model_small_72x88.npz", True), ("model_small_128.npz", False),
-               ("model_full_64.npz", True), ("model_full_128.npz", False)]
+               ("model_full_64.npz", True), ("model_full_128.npz", False), ("model_full_128_bwd.npz", True),
+               ("model_small_64_bias.npz", True)]
 
 
 @pytest.mark.parametrize("fname,backward", MODEL_CASES)
@@ -50,7 +51,8 @@ def test_model_matches_reference(fname, backward):
     z = util.load_npz(fname)
     ctor = json.loads(str(z["ctor"]))
     seed = int(z["seed"])
-    shapes = util.small_model_shapes(ctor.get("num_blocks", (4, 6, 6, 8)), ctor.get("num_refinement_blocks", 4))
+    shapes = util.small_model_shapes(ctor.get("num_blocks", (4, 6, 6, 8)), ctor.get("num_refinement_blocks", 4),
+                                     bias=ctor.get("bias", False))
     params = util.params_for(shapes, seed, requires_grad=backward)
     x = torch.from_numpy(z["x"])
     with torch.set_grad_enabled(backward):
@@ -64,9 +66,13 @@ def test_model_matches_reference(fname, backward):
         assert n > 100
 
 
-def _module_tags():
-    z = util.load_npz("modules.npz")
+def _module_tags(fname="modules.npz"):
+    z = util.load_npz(fname)
     return sorted({k.split("/")[0] for k in z.files})
+
+
+def _module_file(tag):
+    return "modules_bias.npz" if tag.endswith("_bias") else "modules.npz"
 
 
 def _run_module(tag, p, x):
@@ -90,9 +96,9 @@ def _run_module(tag, p, x):
     raise KeyError(tag)
 
 
-@pytest.mark.parametrize("tag", _module_tags())
+@pytest.mark.parametrize("tag", _module_tags() + _module_tags("modules_bias.npz"))
 def test_module_matches_reference(tag):
-    z = util.load_npz("modules.npz")
+    z = util.load_npz(_module_file(tag))
     shapes = {k: tuple(v) for k, v in json.loads(str(z[f"{tag}/param_shapes"])).items()}
     p = util.params_for(shapes, 7, prefix=tag + "/", requires_grad=True)
     y_ref = z[f"{tag}/y"]

@@ -74,3 +74,134 @@ def test_graph_and_part_streams_match_the_eager_step():
         assert np.allclose(losses, ref_losses, rtol=0, atol=2e-6), (losses, ref_losses)
         assert float((grad - ref_grad).abs().max()) <= 2e-5 * float(ref_grad.abs().max())
         assert float((param - ref_param).abs().max()) <= 2e-6
+
+
+def _check_flat_grads(z, trainer):
+    import json
+
+    names = json.loads(str(z["grad_names"]))
+    norms, probes = z["grad_norm"], z["grad_probe"]
+    scale = float(np.nanmax(norms))
+    grads = {n: p.grad for n, p in trainer.opt.named}
+    checked = 0
+    for name, gn, gp in zip(names, norms, probes):
+        if np.isnan(gn):
+            assert name not in grads, name    # the six parameters the reference never uses
+            continue
+        n, d = util.grad_probe(name, grads[name])
+        tol = 5e-4 * max(gn, 1e-3 * scale)
+        assert abs(n - gn) <= tol, (name, n, gn)
+        assert abs(d - gp) <= tol, (name, d, gp)
+        key = f"grad/{name}"
+        if key in z.files:
+            ref = z[key]
+            assert float(np.abs(grads[name].cpu().numpy() - ref).max()) <= 5e-4 * max(float(np.abs(ref).max()), 1e-3 * scale), name
+        checked += 1
+    return checked
+
+
+def test_config3_shapes_in_the_bench_execution_mode():
+    """Full-depth network, batch 16 x 128x128, through DataParallelTrainer(graph=True, micro_streams=4) - the exact
+    execution mode of bench.py (hipGraph replay, four part-batch streams) - against loss and gradient summaries of
+    the REAL reference (tests/golden/model_full_128_b16.npz, oracle/make_golden.py config3).  Compared BEFORE the
+    optimiser step: `_fwd_bwd` through the captured graph leaves the batch-mean gradient in the flat buffer."""
+    import json
+
+    from net.model import PromptIR
+    from promptir_amd.train import DataParallelTrainer
+
+    dev = torch.device("cuda:0")
+    z = util.load_npz("model_full_128_b16.npz")
+    seed, batch = int(z["seed"]), int(z["batch"])
+    net = PromptIR(**json.loads(str(z["ctor"])))
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(util.params_for(shapes, seed))
+    net.to(dev)
+    degraded, clean = W.synthetic_pair(batch, int(z["size"][0]), int(z["size"][1]), sigma=[int(s) for s in z["sigmas"]],
+                                       seed=seed)
+    x, t = torch.from_numpy(degraded).to(dev), torch.from_numpy(clean).to(dev)
+    trainer = DataParallelTrainer(net, lr=2e-4, graph=True, micro_streams=4)
+    trainer.prepare(x, t)
+    assert trainer.graph and trainer._graph is not None and trainer.micro_streams == 4   # no silent eager fallback
+    loss = trainer.forward_backward(x, t)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(z["loss"])) <= 2e-6
+    assert _check_flat_grads(z, trainer) > 500
+    # a full step on top still runs (all-reduce no-op, AdamW, weight re-split) and the next replay sees the new weights
+    l1 = float(trainer.train_step(x, t))
+    l2 = float(trainer.train_step(x, t))
+    assert abs(l1 - float(z["loss"])) <= 2e-6 and l2 < l1
+
+
+def test_capture_refusal_falls_back_to_the_eager_step(monkeypatch):
+    """only a capture-specific refusal may fall back (with a warning) to the eager single-stream step,
+    and that fallback must compute the same step; any other error of the warm-up / step propagates."""
+    from net.model import PromptIR
+    from promptir_amd import train as T
+
+    dev = torch.device("cuda:0")
+    ctor = dict(decoder=True, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1)
+    degraded, clean = W.synthetic_pair(8, 64, 64, sigma=25, seed=6)
+    x, t = torch.from_numpy(degraded).to(dev), torch.from_numpy(clean).to(dev)
+
+    def make(graph, streams):
+        net = PromptIR(**ctor)
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        net.load_state_dict(util.params_for(shapes, 13))
+        return T.DataParallelTrainer(net.to(dev), lr=2e-4, micro_streams=streams, graph=graph)
+
+    ref = make(False, 1)
+    ref_losses = [float(ref.train_step(x, t)) for _ in range(2)]
+
+    class Refuse:
+        def __init__(self, *a, **k):
+            pass
+
+        def __enter__(self):
+            raise RuntimeError("hipGraph capture refused by the runtime (test)")
+
+        def __exit__(self, *a):
+            return False
+
+    tr = make(True, 2)
+    monkeypatch.setattr(torch.cuda, "graph", Refuse)
+    with pytest.warns(UserWarning, match="capture refused"):
+        losses = [float(tr.train_step(x, t)) for _ in range(2)]
+    assert tr.graph is False and tr.micro_streams == 1
+    assert np.allclose(losses, ref_losses, rtol=0, atol=2e-6)
+    assert float((tr.opt.param - ref.opt.param).abs().max()) <= 2e-6
+
+    class Broken(Refuse):
+        def __enter__(self):
+            raise RuntimeError("invalid argument")   # not a capture refusal: must propagate
+
+    tr2 = make(True, 2)
+    monkeypatch.setattr(torch.cuda, "graph", Broken)
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        tr2.train_step(x, t)
+
+
+def test_replay_sees_weights_changed_behind_its_back():
+    """a captured graph holds no Python, so a weight update that bypasses the trainer
+    (load_state_dict / a checkpoint / a broadcast) must still reach the pre-split bf16x3 pieces before the replay."""
+    from net.model import PromptIR
+    from promptir_amd.train import DataParallelTrainer
+
+    dev = torch.device("cuda:0")
+    ctor = dict(decoder=True, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1)
+    degraded, clean = W.synthetic_pair(4, 64, 64, sigma=25, seed=2)
+    x, t = torch.from_numpy(degraded).to(dev), torch.from_numpy(clean).to(dev)
+    net = PromptIR(**ctor)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(util.params_for(shapes, 1))
+    tr = DataParallelTrainer(net.to(dev), lr=2e-4, graph=True, micro_streams=1)
+    tr.forward_backward(x, t)
+    new = util.params_for(shapes, 2)
+    net.load_state_dict(new)                       # in-place copy into the flat buffer views
+    loss_graph = float(tr.forward_backward(x, t))
+    net2 = PromptIR(**ctor)
+    net2.load_state_dict(new)
+    eager = DataParallelTrainer(net2.to(dev), lr=2e-4, graph=False, micro_streams=1)
+    loss_eager = float(eager.forward_backward(x, t))
+    assert abs(loss_graph - loss_eager) <= 2e-6
+    assert float((tr.opt.grad - eager.opt.grad).abs().max()) <= 2e-5 * float(eager.opt.grad.abs().max())

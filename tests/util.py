@@ -48,8 +48,21 @@ def grad_probe(name: str, grad: torch.Tensor):
     return float(np.sqrt((g * g).sum())), float((g * probe(name, g.size)).sum())
 
 
-def small_model_shapes(num_blocks=(1, 1, 1, 1), num_refinement_blocks=1) -> Dict[str, tuple]:
-    """Shapes of a reduced-depth network, derived from the default one by dropping block indices."""
+def small_model_shapes(num_blocks=(1, 1, 1, 1), num_refinement_blocks=1, bias=False) -> Dict[str, tuple]:
+    """Shapes of a reduced-depth network, derived from the default one by dropping block indices.  bias=True adds a
+    `.bias` [Cout] after every convolution weight the reference builds with `bias=bias` (state_dict_shapes_bias.json
+    lists those keys for the default depth)."""
+    if bias:
+        with open(os.path.join(GOLDEN, "state_dict_shapes_bias.json")) as f:
+            keys = json.load(f)["keys"]
+        base = small_model_shapes(num_blocks, num_refinement_blocks)
+        out = {}
+        for k in keys:
+            if k in base:
+                out[k] = base[k]
+            elif k.endswith(".bias") and k[:-5] + ".weight" in base and k not in full_shapes():
+                out[k] = (base[k[:-5] + ".weight"][0],)
+        return out
     stages = {"encoder_level1": num_blocks[0], "encoder_level2": num_blocks[1], "encoder_level3": num_blocks[2],
               "latent": num_blocks[3], "decoder_level3": num_blocks[2], "decoder_level2": num_blocks[1],
               "decoder_level1": num_blocks[0], "refinement": num_refinement_blocks}

@@ -46,7 +46,8 @@ def main():
         raise SystemExit("only --model promptir is built (SURVEY §2: sibling networks are out of scope)")
     from net.model import PromptIR
     from promptir_amd import data as D
-    from promptir_amd.train import DataParallelTrainer, init_distributed, load_lightning_checkpoint, warmup_cosine_lr
+    from promptir_amd.train import (DataParallelTrainer, init_distributed, load_checkpoint_file, load_lightning_checkpoint,
+                                    lightning_epoch_lr)
 
     rank, local, world = init_distributed()
     if not torch.cuda.is_available():
@@ -58,12 +59,14 @@ def main():
     else:
         dataset = D.SyntheticTrainSet(opt.synthetic or 64 * opt.batch_size * world, opt.patch_size, de_ids or [0, 1, 2])
     if rank == 0:
-        print(f"[train] {type(dataset).__name__} with {len(dataset)} samples, world {world}, batch {opt.batch_size}/GPU")
+        pg = torch.distributed.get_backend() if torch.distributed.is_initialized() else "none"
+        print(f"[train] {type(dataset).__name__} with {len(dataset)} samples, world {world}, batch {opt.batch_size}/GPU, "
+              f"process group {pg}")
 
     net = PromptIR(decoder=True)
     start_epoch, ckpt = 0, None
     if opt.resume:
-        ckpt = torch.load(opt.resume, map_location="cpu")
+        ckpt = load_checkpoint_file(opt.resume)
         load_lightning_checkpoint(net, ckpt)
         start_epoch = int(ckpt.get("epoch", -1)) + 1
     if opt.start_epoch is not None:
@@ -71,12 +74,12 @@ def main():
     net.to(device)
     trainer = DataParallelTrainer(net)
     if ckpt is not None and ckpt.get("optimizer_states"):
-        trainer.opt.load_state_dict(ckpt["optimizer_states"][0])
+        trainer.opt.load_state_dict(ckpt["optimizer_states"][0], net)   # flat or torch/Lightning AdamW layout
     os.makedirs(opt.ckpt_dir, exist_ok=True)
 
     steps = 0
     for epoch in range(start_epoch, opt.epochs):
-        lr = warmup_cosine_lr(epoch)                      # utils/schedulers.py:332-346 via train.py:48-50
+        lr = lightning_epoch_lr(epoch)                    # utils/schedulers.py:332-346 via train.py:48-50
         idx = D.shard_indices(len(dataset), rank, world, epoch)
         idx = idx[: len(idx) // opt.batch_size * opt.batch_size]   # drop_last=True (train.py:336)
         t0, running, nb = time.time(), 0.0, 0
@@ -95,10 +98,10 @@ def main():
             print(f"[train] epoch {epoch} lr {lr:.3e} train_loss {running / max(nb, 1):.5f} "
                   f"{nb * opt.batch_size * world / max(dt, 1e-9):.1f} patches/s")
             path = os.path.join(opt.ckpt_dir, f"epoch={epoch}-step={trainer.opt.steps}.ckpt")
-            torch.save(trainer.checkpoint(epoch), path)
+            torch.save(trainer.checkpoint(epoch, lr), path)
         if opt.max_steps and steps >= opt.max_steps:
             break
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 
