@@ -39,7 +39,9 @@ const char* pir_arch(void);
 
 /* tuning / A-B knob used by tools/ktune.py: knob 0 = gemm_nn tile config, 1 = gemm_nt tile config,
  * 2 = gemm_nt split count, 3 / 4 = force (1) or forbid (0) the bf16x3 matrix-core path of gemm_nn / gemm_nt;
- * value -1 (0 for knob 2) restores the built-in policy. */
+ * value -1 (0 for knob 2) restores the built-in policy.  6 = rows per band of the register-only GDFN backward
+ * (0 = automatic), 7 = 1 disables that kernel (A/B against the LDS-tiled one).  Process-wide development switches:
+ * set them before the first launch, never while another thread is launching. */
 int pir_tune_set(int knob, int value);
 
 /* ------------------------------------------------------------------ GEMM core

@@ -228,6 +228,246 @@ __global__ __launch_bounds__(256) void gdfn_dw_bwd_kernel(GArgs a) {
   else if (threadIdx.x < 18) wp[(c + a.hid) * 9 + threadIdx.x - 9] = tot;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Wave-autonomous variant (no LDS, no barriers) for power-of-two image widths.
+//
+// A "unit" is one (image, hidden-channel pair, band of RB rows); W/VEC adjacent lanes own VEC columns each of the
+// unit and slide down its rows with everything in registers: the x window (3 rows), the dt window (3 rows), the
+// taps and the 18 weight-gradient sums.  The one-column halos come from the neighbouring lanes through DPP wave
+// shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1) = the convolution's zero padding at the unit's edges.
+// Every global access is a coalesced VEC*4-byte load/store of a whole image row segment; rows are prefetched three
+// ahead into registers.  UNI: the unit fills the wave (W = 64*VEC) - taps are wave-uniform (SGPRs) and the DPP
+// bound control supplies the edge zeros; otherwise 64*VEC/W units share a wave, taps sit in VGPRs and the unit
+// edges are masked.  Per output row and plane pair: 3 row loads, 2 row stores - the algorithmic 5 planes - plus the
+// band halos (x rows r0-2, r0-1, r0+RB, r0+RB+1 and dg rows r0-1, r0+RB are read by two bands).
+struct GWArgs {
+  const float* x; long x_bs;
+  const float* w;
+  const float* dg; long dg_bs;
+  float* dx; long dx_bs;
+  float* ws;
+  int B, hid, H, W;
+  int lpu_shift, RB, nbands;
+  long npairs;
+};
+
+__device__ __forceinline__ float dpp_from_lower(float v) {   // value held by lane - 1 (0 for lane 0)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_from_upper(float v) {   // value held by lane + 1 (0 for lane 63)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+
+// gelu_erf(v) and its derivative, branch-free: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, the size of
+// fp32 rounding of the cdf), sharing its exp(-v^2/2) with the pdf term.  ~17 VALU + v_rcp + v_exp instead of libm's
+// erff + expf; only used in backward kernels (the forward keeps libm erff).  Checked against fp64 in tests.
+__device__ __forceinline__ void gelu_both_fast(float v, float& g, float& dg) {
+  const float ax = fabsf(v) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  const float e = __expf(-ax * ax);                     // = exp(-v^2 / 2)
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float erf_abs = fmaf(-p * t, e, 1.f);
+  const float cdf = fmaf(0.5f, copysignf(erf_abs, v), 0.5f);
+  g = v * cdf;
+  dg = fmaf(v * 0.39894228040143267794f, e, cdf);
+}
+
+template <int VEC>
+__device__ __forceinline__ void row_load(const float* __restrict__ p, bool ok, float (&out)[VEC]) {
+  if (VEC == 4) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (ok) v = *reinterpret_cast<const f32x4*>(p);
+    out[0] = v[0]; out[1 % VEC] = v[1]; out[2 % VEC] = v[2]; out[VEC - 1] = v[3];
+  } else if (VEC == 2) {
+    float2 v = {0.f, 0.f};
+    if (ok) v = *reinterpret_cast<const float2*>(p);
+    out[0] = v.x; out[VEC - 1] = v.y;
+  } else {
+    out[0] = ok ? p[0] : 0.f;
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void row_store(float* __restrict__ p, const float (&v)[VEC]) {
+  if (VEC == 4) { f32x4 t = {v[0], v[1 % VEC], v[2 % VEC], v[VEC - 1]}; *reinterpret_cast<f32x4*>(p) = t; }
+  else if (VEC == 2) { float2 t = {v[0], v[VEC - 1]}; *reinterpret_cast<float2*>(p) = t; }
+  else p[0] = v[0];
+}
+
+template <int VEC, bool UNI>
+__global__ __launch_bounds__(256, (VEC == 2 ? 3 : 4)) void gdfn_dw_bwd_wave_kernel(GWArgs a) {
+  constexpr int WD = VEC + 2;
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lpu = 1 << a.lpu_shift, upw = 64 >> a.lpu_shift;
+  const int band = (int)(wave % a.nbands);
+  const long pair = (wave / a.nbands) * upw + (UNI ? 0 : (lane >> a.lpu_shift));
+  const int q = UNI ? lane : (lane & (lpu - 1));
+  const bool lane_ok = pair < a.npairs;
+  const long pc = lane_ok ? pair : 0;
+  const int b = (int)(pc / a.hid), c = (int)(pc % a.hid);
+  const bool has_left = q != 0, has_right = q != lpu - 1;
+  const int W = a.W, H = a.H;
+  const long HW = (long)H * W;
+  const int r0 = band * a.RB;
+  const int rb = (r0 + a.RB <= H) ? a.RB : H - r0;      // rows of this band (wave-uniform)
+  const float* __restrict__ x1p = a.x + b * a.x_bs + c * HW + q * VEC;
+  const float* __restrict__ x2p = x1p + a.hid * HW;
+  const float* __restrict__ dgp = a.dg + b * a.dg_bs + c * HW + q * VEC;
+  float* __restrict__ o1p = a.dx + b * a.dx_bs + c * HW + q * VEC;
+  float* __restrict__ o2p = o1p + a.hid * HW;
+
+  float k1[9], k2[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    k1[t] = a.w[c * 9 + t]; k2[t] = a.w[(c + a.hid) * 9 + t];
+    if (UNI) {   // one unit per wave: the taps are wave-uniform, keep them in scalar registers
+      k1[t] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, k1[t])));
+      k2[t] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, k2[t])));
+    }
+  }
+  float ws1[9], ws2[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) { ws1[t] = 0.f; ws2[t] = 0.f; }
+
+  // windows, slot = (row - (r0 - 2)) % 3 for x rows; dt row y = r0 - 1 + i lives in slot (i + 1) % 3
+  float X1[3][WD], X2[3][WD], D1[3][WD], D2[3][WD];
+  float P1[3][VEC], P2[3][VEC], PG[3][VEC];
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int j = 0; j < WD; ++j) { X1[s][j] = 0.f; X2[s][j] = 0.f; D1[s][j] = 0.f; D2[s][j] = 0.f; }
+
+  const int x_last = r0 + rb + 1 < H ? r0 + rb + 1 : H - 1;   // last x row this band touches
+  const int g_last = r0 + rb < H ? r0 + rb : H - 1;           // last dg row
+  auto load_x = [&](int row, float (&d1)[VEC], float (&d2)[VEC]) {
+    const bool ok = lane_ok && row >= 0 && row <= x_last;
+    const long off = (long)row * W;
+    row_load<VEC>(x1p + off, ok, d1);
+    row_load<VEC>(x2p + off, ok, d2);
+  };
+  auto load_g = [&](int row, float (&d)[VEC]) {
+    const bool ok = lane_ok && row >= 0 && row <= g_last;
+    row_load<VEC>(dgp + (long)row * W, ok, d);
+  };
+  auto widen = [&](const float (&raw)[VEC], float (&wide)[WD]) {   // [left halo, own columns, right halo]
+    const float l = dpp_from_lower(raw[VEC - 1]), r = dpp_from_upper(raw[0]);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) wide[j + 1] = raw[j];
+    wide[0] = (UNI || has_left) ? l : 0.f;       // UNI: lanes 0 / 63 get the DPP bound-control zero
+    wide[WD - 1] = (UNI || has_right) ? r : 0.f;
+  };
+
+  {  // prologue: x rows r0-2, r0-1 into slots 0, 1; rows r0, r0+1, r0+2 and dg rows r0-1, r0, r0+1 in flight
+    float t1[VEC], t2[VEC];
+    load_x(r0 - 2, t1, t2); widen(t1, X1[0]); widen(t2, X2[0]);
+    load_x(r0 - 1, t1, t2); widen(t1, X1[1]); widen(t2, X2[1]);
+    load_x(r0, P1[2], P2[2]); load_x(r0 + 1, P1[0], P2[0]); load_x(r0 + 2, P1[1], P2[1]);
+    load_g(r0 - 1, PG[0]); load_g(r0, PG[1]); load_g(r0 + 1, PG[2]);
+  }
+
+  // one dt row per step; PH = i % 3 fixes every window slot at compile time
+#define PIR_GW_STEP(PH)                                                                                         \
+  if (i <= rb + 1) {                                                                                            \
+    constexpr int S0 = (PH) % 3, S1 = ((PH) + 1) % 3, S2 = ((PH) + 2) % 3;                                      \
+    const int y = r0 - 1 + i;                                                                                   \
+    widen(P1[S2], X1[S2]); widen(P2[S2], X2[S2]);              /* x row y + 1 */                                \
+    float g[VEC];                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < VEC; ++j) g[j] = PG[S0][j];                                           \
+    load_x(y + 4, P1[S2], P2[S2]);                              /* refill the slots just consumed */            \
+    load_g(y + 3, PG[S0]);                                                                                      \
+    float d1[VEC], d2[VEC];                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < VEC; ++j) {                                                           \
+      float t1 = 0.f, t2 = 0.f;                                                                                 \
+      _Pragma("unroll") for (int d = 0; d < 3; ++d) {                                                           \
+        t1 += k1[d] * X1[S0][j + d] + k1[3 + d] * X1[S1][j + d] + k1[6 + d] * X1[S2][j + d];                    \
+        t2 += k2[d] * X2[S0][j + d] + k2[3 + d] * X2[S1][j + d] + k2[6 + d] * X2[S2][j + d];                    \
+      }                                                                                                         \
+      float ge, gd;                                                                                             \
+      gelu_both_fast(t1, ge, gd);                                                                               \
+      d1[j] = g[j] * t2 * gd;                                                                                   \
+      d2[j] = g[j] * ge;                                                                                        \
+    }                                                                                                           \
+    widen(d1, D1[S1]); widen(d2, D2[S1]);                       /* dt row y */                                  \
+    if (i >= 1 && i <= rb) {                                    /* rows of this band: weight-gradient sums */   \
+      _Pragma("unroll") for (int j = 0; j < VEC; ++j)                                                           \
+        _Pragma("unroll") for (int d = 0; d < 3; ++d) {                                                         \
+          ws1[d] += d1[j] * X1[S0][j + d]; ws1[3 + d] += d1[j] * X1[S1][j + d]; ws1[6 + d] += d1[j] * X1[S2][j + d]; \
+          ws2[d] += d2[j] * X2[S0][j + d]; ws2[3 + d] += d2[j] * X2[S1][j + d]; ws2[6 + d] += d2[j] * X2[S2][j + d]; \
+        }                                                                                                       \
+    }                                                                                                           \
+    if (i >= 2) {                                               /* dx row y - 1 from dt rows y-2, y-1, y */     \
+      float o1[VEC], o2[VEC];                                                                                   \
+      _Pragma("unroll") for (int j = 0; j < VEC; ++j) {                                                         \
+        float s1 = 0.f, s2 = 0.f;                                                                               \
+        _Pragma("unroll") for (int d = 0; d < 3; ++d) {                                                         \
+          s1 += k1[8 - d] * D1[S2][j + d] + k1[5 - d] * D1[S0][j + d] + k1[2 - d] * D1[S1][j + d];              \
+          s2 += k2[8 - d] * D2[S2][j + d] + k2[5 - d] * D2[S0][j + d] + k2[2 - d] * D2[S1][j + d];              \
+        }                                                                                                       \
+        o1[j] = s1; o2[j] = s2;                                                                                 \
+      }                                                                                                         \
+      if (lane_ok) {                                                                                            \
+        const long off = (long)(y - 1) * W;                                                                     \
+        row_store<VEC>(o1p + off, o1);                                                                          \
+        row_store<VEC>(o2p + off, o2);                                                                          \
+      }                                                                                                         \
+    }                                                                                                           \
+  }                                                                                                             \
+  ++i;
+
+  for (int i = 0; i <= rb + 1;) {
+    PIR_GW_STEP(0)
+    PIR_GW_STEP(1)
+    PIR_GW_STEP(2)
+  }
+#undef PIR_GW_STEP
+
+  // weight-gradient sums of the unit: butterfly over its lanes, lane 0 of the unit writes the band's partial
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float v1 = ws1[t], v2 = ws2[t];
+    for (int off = lpu >> 1; off > 0; off >>= 1) { v1 += __shfl_xor(v1, off, 64); v2 += __shfl_xor(v2, off, 64); }
+    ws1[t] = v1; ws2[t] = v2;
+  }
+  if (lane_ok && q == 0) {
+    float* wp = a.ws + ((long)b * a.nbands + band) * (2L * a.hid * 9);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { wp[c * 9 + t] = ws1[t]; wp[(c + a.hid) * 9 + t] = ws2[t]; }
+  }
+}
+
+struct GWPlan { int vec, lpu_shift, RB, nbands; long waves; bool ok; };
+
+int g_gw_rb = 0, g_gw_off = 0;   // development overrides (pir_tune_set knobs 6, 7)
+
+// W = 128 / 64: one unit per wave (2 / 1 columns per lane); narrower planes: one column per lane, 64 / W units per
+// wave.  (Four columns per lane need > 168 registers: W = 256 stays on the LDS-tiled kernel.)  Bands of 32 rows,
+// halved while the launch has too few waves to fill the chip.
+GWPlan gwplan(int B, int hid, int H, int W) {
+  GWPlan p = {0, 0, 0, 0, 0, false};
+  if (g_gw_off || W < 4 || W > 128 || (W & (W - 1)) != 0) return p;
+  const long npairs = (long)B * hid;
+  const int vec = W == 128 ? 2 : 1;
+  p.vec = vec;
+  const int lpu = W / vec;
+  int sh = 0;
+  while ((1 << sh) < lpu) ++sh;
+  p.lpu_shift = sh;
+  const long groups = pir_cdiv(npairs, 64 / lpu);
+  int rb = 32;
+  while (rb > 8 && groups * pir_cdiv(H, rb) < 3072) rb >>= 1;
+  if (g_gw_rb) rb = g_gw_rb;
+  if (rb > H) rb = H;
+  p.RB = rb;
+  p.nbands = (int)pir_cdiv(H, rb);
+  p.waves = groups * p.nbands;
+  p.ok = true;
+  return p;
+}
+
 struct GPlan { int CT, LPR, threads, strips, SR, RT, tiles_r, tiles_c; size_t lds_bytes; };
 
 GPlan gplan(int H, int W) {
@@ -262,11 +502,20 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 }  // namespace
 
+extern "C" int pir_reduce_partials(const float* parts, long stride, int S, float alpha, int accumulate,
+                                   float* out, long count, pir_stream_t stream);
+int pir_gdfn_wave_tune(int knob, int value) {
+  if (knob == 6) g_gw_rb = value; else if (knob == 7) g_gw_off = value; else return PIR_EINVAL;
+  return PIR_OK;
+}
+
 extern "C" size_t pir_gdfn_dwconv_bwd_ws_floats(int B, int hid, int H, int W) {
   if (B <= 0 || hid <= 0 || H <= 0 || W <= 0) return 0;
   // fused path: partial sums; fallback path (W % 4 != 0 / unaligned): a dt buffer + the wgrad partials
   GPlan p = gplan(H, W % 4 == 0 ? W : 4);
-  const size_t fused = W % 4 == 0 ? (size_t)B * p.tiles_c * 2 * hid * 9 : 0;
+  size_t fused = W % 4 == 0 ? (size_t)B * p.tiles_c * 2 * hid * 9 : 0;
+  const size_t wave = (size_t)B * pir_cdiv(H, 8 < H ? 8 : H) * 2 * hid * 9;   // most bands the wave kernel ever uses
+  if (wave > fused) fused = wave;
   const size_t fallback = (size_t)B * 2 * hid * H * W + pir_dwconv3x3_wgrad_ws_floats(B, 2 * hid, H, W);
   return fused > fallback ? fused : fallback;
 }
@@ -286,6 +535,27 @@ extern "C" int pir_gdfn_dwconv_bwd(const float* x, long x_bs, const float* w, co
     st = pir_dwconv3x3(dt, dt_bs, w, 1, dx, dx_bs, B, 2 * hid, H, W, stream);
     if (st) return st;
     return pir_dwconv3x3_wgrad(dt, dt_bs, x, x_bs, dw, ws + dt_floats, ws_floats - dt_floats, B, 2 * hid, H, W, stream);
+  }
+  const GWPlan gw = gwplan(B, hid, H, W);
+  if (gw.ok && (gw.vec == 1 || (x_bs % gw.vec == 0 && dg_bs % gw.vec == 0 && dx_bs % gw.vec == 0 &&
+                               (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dg) | reinterpret_cast<uintptr_t>(dx)) % (4 * gw.vec) == 0))) {   // register-only sliding-window kernel
+    const long parts = (long)B * gw.nbands;
+    if ((size_t)parts * 2 * hid * 9 > ws_floats) return PIR_ENOMEM;
+    GWArgs g;
+    g.x = x; g.x_bs = x_bs; g.w = w; g.dg = dg; g.dg_bs = dg_bs; g.dx = dx; g.dx_bs = dx_bs; g.ws = ws;
+    g.B = B; g.hid = hid; g.H = H; g.W = W; g.lpu_shift = gw.lpu_shift; g.RB = gw.RB; g.nbands = gw.nbands;
+    g.npairs = (long)B * hid;
+    const long blocks = pir_cdiv(gw.waves, 4);
+    if (blocks > 2147483647L) return PIR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const bool uni = gw.lpu_shift == 6;
+    const dim3 grid((unsigned)blocks), blk(256);
+    if (gw.vec == 2) hipLaunchKernelGGL((gdfn_dw_bwd_wave_kernel<2, true>), grid, blk, 0, s, g);
+    else if (uni) hipLaunchKernelGGL((gdfn_dw_bwd_wave_kernel<1, true>), grid, blk, 0, s, g);
+    else hipLaunchKernelGGL((gdfn_dw_bwd_wave_kernel<1, false>), grid, blk, 0, s, g);
+    int st = pir_launch_status();
+    if (st) return st;
+    return pir_reduce_partials(ws, 2L * hid * 9, (int)parts, 1.f, 0, dw, 2L * hid * 9, stream);
   }
   GPlan p = gplan(H, W);
   const long parts = (long)B * p.tiles_c;

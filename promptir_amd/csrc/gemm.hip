@@ -852,6 +852,8 @@ int launch_nt(NTParams& p, size_t ws_floats, int tap_sign, long g_st, hipStream_
 
 }  // namespace
 
+int pir_gdfn_wave_tune(int knob, int value);   // gdfn_bwd.hip
+
 extern "C" int pir_tune_set(int knob, int value) {
   switch (knob) {
     case 0: g_nn_cfg = value; return PIR_OK;
@@ -859,6 +861,7 @@ extern "C" int pir_tune_set(int knob, int value) {
     case 2: g_nt_splits = value; return PIR_OK;
     case 3: g_nn_x3 = value; return PIR_OK;
     case 4: g_nt_x3 = value; return PIR_OK;
+    case 6: case 7: return pir_gdfn_wave_tune(knob, value);
     default: return PIR_EINVAL;
   }
 }

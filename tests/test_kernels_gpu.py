@@ -146,10 +146,12 @@ def test_dwconv_gate(b, hid, h, w):
 
 
 @pytest.mark.parametrize("b,hid,h,w", [(2, 5, 16, 16), (1, 127, 9, 11), (1, 3, 128, 128), (2, 2, 40, 256), (1, 4, 8, 8),
-                                       (1, 2, 70, 300), (3, 3, 1, 4)])
+                                       (1, 2, 70, 300), (3, 3, 1, 4), (2, 3, 64, 64), (1, 2, 33, 32), (3, 7, 128, 128),
+                                       (1, 5, 20, 16), (2, 9, 37, 64), (1, 1, 2, 8)])
 def test_fused_stencil_backwards(b, hid, h, w):
-    """pir_gdfn_dwconv_bwd and pir_dwconv3x3_bwd vs autograd of the unfused PyTorch ops (incl. multi-tile and
-    the W % 4 != 0 fallback)."""
+    """pir_gdfn_dwconv_bwd and pir_dwconv3x3_bwd vs autograd of the unfused PyTorch ops (incl. multi-tile, the
+    W % 4 != 0 fallback, and the register-only wave kernels: power-of-two widths <= 128, ragged heights, several
+    units per wave with idle lanes, bands that end inside the image)."""
     from promptir_amd import ops
 
     x, wt, dg = rnd("x", b, 2 * hid, h, w), rnd("w", 2 * hid, 1, 3, 3), rnd("dg", b, hid, h, w)
