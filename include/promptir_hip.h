@@ -169,6 +169,14 @@ int pir_layernorm_bwd(const float* dy, long dy_bs, const float* x, long x_bs, co
  */
 int pir_dwconv3x3(const float* x, long x_bs, const float* w, int flip, float* y, long y_bs,
                   int B, int C, int H, int W, pir_stream_t stream);
+/* The same stencil (flip=0) that also leaves the squared L2 norms of its first nsq output channels, which
+ * F.normalize needs for q and k (net/model.py:127-128: nsq = 2*dim of the 3*dim qkv channels), so q and k are not
+ * read a second time: sq_parts[b][p][ch] (ch < nsq, p < *nparts) are partial sums of y[b][ch]^2 over the row bands of
+ * the plane; the consumer (pir_mdta_softmax_fwd / _bwd) adds the *nparts slices in order.  *nparts (host int, written
+ * before returning) depends only on the shape and alignment.  sq_parts holds pir_dwconv3x3_sumsq_floats() floats. */
+size_t pir_dwconv3x3_sumsq_floats(int B, int nsq, int H);
+int pir_dwconv3x3_sumsq(const float* x, long x_bs, const float* w, float* y, long y_bs, float* sq_parts,
+                        size_t sq_floats, int nsq, int* nparts, int B, int C, int H, int W, pir_stream_t stream);
 /* Fused GDFN tail: t = dwconv(x) on 2*hid channels; g = gelu_erf(t[:hid]) * t[hid:]
  * (net/model.py:96-97).  Writes g ([B][hid][H][W]). */
 int pir_dwconv3x3_gate(const float* x, long x_bs, const float* w, float* g, long g_bs,
@@ -190,7 +198,8 @@ int pir_dwconv3x3_bwd(const float* dy, long dy_bs, const float* x, long x_bs, co
                       int B, int C, int H, int W, pir_stream_t stream);
 /* Fused backward of the GDFN tail (net/model.py:96-97): from x = project_in output ([B][2hid]) and dg
  * ([B][hid]) to dx ([B][2hid]) and the depthwise weight gradient dw ([2hid][9]) in ONE pass:
- * the pre-gate tensor t = dwconv(x) and dt are recomputed on a halo-extended tile in LDS. */
+ * the pre-gate tensor t = dwconv(x) and dt are recomputed, never stored.  Power-of-two widths <= 128 run a
+ * register-only sliding-window kernel (3-row windows per lane, DPP halos, no LDS); other shapes an LDS-tiled one. */
 size_t pir_gdfn_dwconv_bwd_ws_floats(int B, int hid, int H, int W);
 int pir_gdfn_dwconv_bwd(const float* x, long x_bs, const float* w, const float* dg, long dg_bs,
                         float* dx, long dx_bs, float* dw, float* ws, size_t ws_floats,
@@ -201,8 +210,9 @@ int pir_gdfn_dwconv_bwd(const float* x, long x_bs, const float* w, const float* 
  * L2 norms F.normalize needs, net/model.py:127-128). */
 int pir_row_sumsq(const float* x, long x_bs, float* out, int B, int C, int HW, pir_stream_t stream);
 /* attn[b][h] = softmax_j( G[b][h][i][j] / (max(|q_i|,1e-12) max(|k_j|,1e-12)) * temperature[h] )
- * net/model.py:127-131.  sumsq is [B][2C] (q rows then k rows). */
-int pir_mdta_softmax_fwd(const float* gram, const float* sumsq, const float* temperature,
+ * net/model.py:127-131.  sumsq is [B][nparts][2C] (q rows then k rows; nparts partial sums per row, added in
+ * order: pir_row_sumsq gives nparts = 1, pir_dwconv3x3_sumsq one slice per row band). */
+int pir_mdta_softmax_fwd(const float* gram, const float* sumsq, int nparts, const float* temperature,
                          float* attn, int B, int heads, int c, pir_stream_t stream);
 /* Backward through softmax, temperature and the two normalisations.
  * In: dattn, attn, gram, sumsq, temperature.  Out: dgram ([B][h][c][c], already divided by the
@@ -210,7 +220,7 @@ int pir_mdta_softmax_fwd(const float* gram, const float* sumsq, const float* tem
  *   dq = dgram k + alpha_q * q,  dk = dgram^T q + alpha_k * k,
  * and dtemp_partial[b][h] (summed over b by pir_reduce_partials).  c <= 256. */
 int pir_mdta_softmax_bwd(const float* dattn, const float* attn, const float* gram, const float* sumsq,
-                         const float* temperature, float* dgram,
+                         int nparts, const float* temperature, float* dgram,
                          float* alpha_q, float* alpha_k, float* dtemp_partial,
                          int B, int heads, int c, pir_stream_t stream);
 

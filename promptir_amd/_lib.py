@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PIR_LIB", os.path.join(_HERE, "libpromptir_hip.so"))  # PIR_LIB: A/B builds in tools/
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_float_p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 c_long = C.c_long
@@ -82,8 +82,10 @@ SIGNATURES = {
     "pir_gdfn_dwconv_bwd_ws_floats": (Z, [I, I, I, I]),
     "pir_gdfn_dwconv_bwd": (I, [P, L, P, P, L, P, L, P, P, Z, I, I, I, I, S]),
     "pir_row_sumsq": (I, [P, L, P, I, I, I, S]),
-    "pir_mdta_softmax_fwd": (I, [P, P, P, P, I, I, I, S]),
-    "pir_mdta_softmax_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, S]),
+    "pir_mdta_softmax_fwd": (I, [P, P, I, P, P, I, I, I, S]),
+    "pir_mdta_softmax_bwd": (I, [P, P, P, P, I, P, P, P, P, P, I, I, I, S]),
+    "pir_dwconv3x3_sumsq_floats": (Z, [I, I, I]),
+    "pir_dwconv3x3_sumsq": (I, [P, L, P, P, L, P, Z, I, C.POINTER(C.c_int), I, I, I, I, S]),
     "pir_pixel_unshuffle2": (I, [P, L, P, L, I, I, I, I, S]),
     "pir_pixel_shuffle2": (I, [P, L, P, L, I, I, I, I, S]),
     "pir_spatial_mean": (I, [P, L, P, I, I, I, S]),

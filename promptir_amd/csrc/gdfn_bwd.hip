@@ -8,6 +8,7 @@
 // (plane pair, tile) in LDS, recomputes t and dt on the 1-pixel-halo-extended tile into LDS, and then
 // produces dx and the weight-gradient partial sums from LDS: 3 planes read + 2 written per hid channel.
 #include "pir_common.h"
+#include "wave_rows.h"
 
 namespace {
 
@@ -252,13 +253,6 @@ struct GWArgs {
   long npairs;
 };
 
-__device__ __forceinline__ float dpp_from_lower(float v) {   // value held by lane - 1 (0 for lane 0)
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float dpp_from_upper(float v) {   // value held by lane + 1 (0 for lane 63)
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
-}
-
 // gelu_erf(v) and its derivative, branch-free: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, the size of
 // fp32 rounding of the cdf), sharing its exp(-v^2/2) with the pdf term.  ~17 VALU + v_rcp + v_exp instead of libm's
 // erff + expf; only used in backward kernels (the forward keeps libm erff).  Checked against fp64 in tests.
@@ -274,27 +268,6 @@ __device__ __forceinline__ void gelu_both_fast(float v, float& g, float& dg) {
   const float cdf = fmaf(0.5f, copysignf(erf_abs, v), 0.5f);
   g = v * cdf;
   dg = fmaf(v * 0.39894228040143267794f, e, cdf);
-}
-
-template <int VEC>
-__device__ __forceinline__ void row_load(const float* __restrict__ p, bool ok, float (&out)[VEC]) {
-  if (VEC == 4) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (ok) v = *reinterpret_cast<const f32x4*>(p);
-    out[0] = v[0]; out[1 % VEC] = v[1]; out[2 % VEC] = v[2]; out[VEC - 1] = v[3];
-  } else if (VEC == 2) {
-    float2 v = {0.f, 0.f};
-    if (ok) v = *reinterpret_cast<const float2*>(p);
-    out[0] = v.x; out[VEC - 1] = v.y;
-  } else {
-    out[0] = ok ? p[0] : 0.f;
-  }
-}
-template <int VEC>
-__device__ __forceinline__ void row_store(float* __restrict__ p, const float (&v)[VEC]) {
-  if (VEC == 4) { f32x4 t = {v[0], v[1 % VEC], v[2 % VEC], v[VEC - 1]}; *reinterpret_cast<f32x4*>(p) = t; }
-  else if (VEC == 2) { float2 t = {v[0], v[VEC - 1]}; *reinterpret_cast<float2*>(p) = t; }
-  else p[0] = v[0];
 }
 
 template <int VEC, bool UNI>

@@ -853,6 +853,7 @@ int launch_nt(NTParams& p, size_t ws_floats, int tap_sign, long g_st, hipStream_
 }  // namespace
 
 int pir_gdfn_wave_tune(int knob, int value);   // gdfn_bwd.hip
+int pir_stencil_wave_tune(int knob, int value);   // stencil_wave.hip
 
 extern "C" int pir_tune_set(int knob, int value) {
   switch (knob) {
@@ -862,6 +863,7 @@ extern "C" int pir_tune_set(int knob, int value) {
     case 3: g_nn_x3 = value; return PIR_OK;
     case 4: g_nt_x3 = value; return PIR_OK;
     case 6: case 7: return pir_gdfn_wave_tune(knob, value);
+    case 8: case 9: case 10: return pir_stencil_wave_tune(knob, value);
     default: return PIR_EINVAL;
   }
 }

@@ -8,29 +8,37 @@ namespace {
 
 constexpr float NORM_EPS = 1e-12f;  // F.normalize default eps
 
+// squared norm of one q / k row = sum of the partial sums the depthwise kernel left per row band
+// (pir_dwconv3x3_sumsq: [image][part][2C]); fixed order, so deterministic
+__device__ __forceinline__ float sum_parts(const float* __restrict__ p, int nparts, int stride) {
+  float s = p[0];
+  for (int k = 1; k < nparts; ++k) s += p[(long)k * stride];
+  return s;
+}
+
 // attn = softmax_j( gram[i][j] / (nq_i nk_j) * temperature ),  n* = max(sqrt(sumsq), eps)
 // 16 waves per map; a row (c <= 256 columns) is loaded ONCE into registers (the kernel is bound by the latency
 // of its dependent global loads, not by arithmetic), the column norms once per wave.
 __global__ __launch_bounds__(1024) void mdta_softmax_fwd_kernel(const float* __restrict__ gram,
                                                                 const float* __restrict__ sumsq,
                                                                 const float* __restrict__ temperature,
-                                                                float* __restrict__ attn, int heads, int c) {
+                                                                float* __restrict__ attn, int heads, int c, int nparts) {
   constexpr int MAXJ = 4;
   const int bh = blockIdx.x, b = bh / heads, h = bh % heads, C = heads * c;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const float* G = gram + (long)bh * c * c;
   float* A = attn + (long)bh * c * c;
-  const float* sq = sumsq + (long)b * 2 * C + h * c;
+  const float* sq = sumsq + (long)b * nparts * 2 * C + h * c;
   const float* sk = sq + C;
   const float t = temperature[h];
   float inv_k[MAXJ];
 #pragma unroll
   for (int u = 0; u < MAXJ; ++u) {
     const int j = lane + 64 * u;
-    inv_k[u] = j < c ? 1.f / fmaxf(sqrtf(sk[j]), NORM_EPS) : 0.f;
+    inv_k[u] = j < c ? 1.f / fmaxf(sqrtf(sum_parts(sk + j, nparts, 2 * C)), NORM_EPS) : 0.f;
   }
   for (int i = wid; i < c; i += nw) {
-    const float inv_q = 1.f / fmaxf(sqrtf(sq[i]), NORM_EPS);
+    const float inv_q = 1.f / fmaxf(sqrtf(sum_parts(sq + i, nparts, 2 * C)), NORM_EPS);
     float sv[MAXJ];
     float m = -INFINITY;
 #pragma unroll
@@ -60,7 +68,8 @@ __global__ __launch_bounds__(1024) void mdta_softmax_fwd_kernel(const float* __r
 __global__ __launch_bounds__(1024) void mdta_softmax_bwd_kernel(
     const float* __restrict__ dattn, const float* __restrict__ attn, const float* __restrict__ gram,
     const float* __restrict__ sumsq, const float* __restrict__ temperature, float* __restrict__ dgram,
-    float* __restrict__ alpha_q, float* __restrict__ alpha_k, float* __restrict__ dtemp_partial, int heads, int c) {
+    float* __restrict__ alpha_q, float* __restrict__ alpha_k, float* __restrict__ dtemp_partial, int heads, int c,
+    int nparts) {
   constexpr int MAXJ = 4;  // c <= 256 columns per lane-strided pass
   __shared__ float colred[16][256];
   __shared__ float red[16];
@@ -70,7 +79,7 @@ __global__ __launch_bounds__(1024) void mdta_softmax_bwd_kernel(
   const float* A = attn + (long)bh * c * c;
   const float* dA = dattn + (long)bh * c * c;
   float* dG = dgram + (long)bh * c * c;
-  const float* sq = sumsq + (long)b * 2 * C + h * c;
+  const float* sq = sumsq + (long)b * nparts * 2 * C + h * c;
   const float* sk = sq + C;
   const float t = temperature[h];
 
@@ -78,12 +87,13 @@ __global__ __launch_bounds__(1024) void mdta_softmax_bwd_kernel(
 #pragma unroll
   for (int u = 0; u < MAXJ; ++u) {
     const int j = lane + 64 * u;
-    inv_k[u] = j < c ? 1.f / fmaxf(sqrtf(sk[j]), NORM_EPS) : 0.f;
+    inv_k[u] = j < c ? 1.f / fmaxf(sqrtf(sum_parts(sk + j, nparts, 2 * C)), NORM_EPS) : 0.f;
     col[u] = 0.f;
   }
   float dt_acc = 0.f;
   for (int i = wid; i < c; i += nw) {
-    const float nq = fmaxf(sqrtf(sq[i]), NORM_EPS);
+    const float sqi = sum_parts(sq + i, nparts, 2 * C);
+    const float nq = fmaxf(sqrtf(sqi), NORM_EPS);
     const float inv_q = 1.f / nq;
     float dot = 0.f, av[MAXJ], dav[MAXJ], gv[MAXJ];   // the row's three operands, loaded once
 #pragma unroll
@@ -110,7 +120,7 @@ __global__ __launch_bounds__(1024) void mdta_softmax_bwd_kernel(
       }
     }
     rowterm = pir_wave_sum(rowterm);
-    if (lane == 0) alpha_q[(long)b * C + h * c + i] = sqrtf(sq[i]) > NORM_EPS ? -rowterm * inv_q * inv_q : 0.f;
+    if (lane == 0) alpha_q[(long)b * C + h * c + i] = sqrtf(sqi) > NORM_EPS ? -rowterm * inv_q * inv_q : 0.f;
   }
 #pragma unroll
   for (int u = 0; u < MAXJ; ++u) colred[wid][lane + 64 * u] = col[u];
@@ -118,8 +128,9 @@ __global__ __launch_bounds__(1024) void mdta_softmax_bwd_kernel(
   for (int j = threadIdx.x; j < c; j += blockDim.x) {
     float s = 0.f;
     for (int w = 0; w < nw; ++w) s += colred[w][j];
-    const float nk = fmaxf(sqrtf(sk[j]), NORM_EPS);
-    alpha_k[(long)b * C + h * c + j] = sqrtf(sk[j]) > NORM_EPS ? -s / (nk * nk) : 0.f;
+    const float skj = sum_parts(sk + j, nparts, 2 * C);
+    const float nk = fmaxf(sqrtf(skj), NORM_EPS);
+    alpha_k[(long)b * C + h * c + j] = sqrtf(skj) > NORM_EPS ? -s / (nk * nk) : 0.f;
   }
   const float dt = pir_block_sum(dt_acc, red);
   if (threadIdx.x == 0) dtemp_partial[bh] = dt;
@@ -127,21 +138,21 @@ __global__ __launch_bounds__(1024) void mdta_softmax_bwd_kernel(
 
 }  // namespace
 
-extern "C" int pir_mdta_softmax_fwd(const float* gram, const float* sumsq, const float* temperature,
+extern "C" int pir_mdta_softmax_fwd(const float* gram, const float* sumsq, int nparts, const float* temperature,
                                     float* attn, int B, int heads, int c, pir_stream_t stream) {
-  PIR_CHECK_ARG(gram && sumsq && temperature && attn && B > 0 && heads > 0 && c > 0 && c <= 256);
+  PIR_CHECK_ARG(gram && sumsq && temperature && attn && B > 0 && heads > 0 && c > 0 && c <= 256 && nparts > 0);
   hipLaunchKernelGGL(mdta_softmax_fwd_kernel, dim3((unsigned)(B * heads)), dim3(1024), 0, (hipStream_t)stream,
-                     gram, sumsq, temperature, attn, heads, c);
+                     gram, sumsq, temperature, attn, heads, c, nparts);
   return pir_launch_status();
 }
 
 extern "C" int pir_mdta_softmax_bwd(const float* dattn, const float* attn, const float* gram, const float* sumsq,
-                                    const float* temperature, float* dgram,
+                                    int nparts, const float* temperature, float* dgram,
                                     float* alpha_q, float* alpha_k, float* dtemp_partial,
                                     int B, int heads, int c, pir_stream_t stream) {
   PIR_CHECK_ARG(dattn && attn && gram && sumsq && temperature && dgram && alpha_q && alpha_k && dtemp_partial);
-  PIR_CHECK_ARG(B > 0 && heads > 0 && c > 0 && c <= 256);
+  PIR_CHECK_ARG(B > 0 && heads > 0 && c > 0 && c <= 256 && nparts > 0);
   hipLaunchKernelGGL(mdta_softmax_bwd_kernel, dim3((unsigned)(B * heads)), dim3(1024), 0, (hipStream_t)stream,
-                     dattn, attn, gram, sumsq, temperature, dgram, alpha_q, alpha_k, dtemp_partial, heads, c);
+                     dattn, attn, gram, sumsq, temperature, dgram, alpha_q, alpha_k, dtemp_partial, heads, c, nparts);
   return pir_launch_status();
 }

@@ -258,6 +258,19 @@ int launch_dw(DwArgs a, bool aligned, hipStream_t s) {
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// ------------------------------------------------------------------------------------ row reductions for the
+// fallback of pir_dwconv3x3_sumsq: out[b][c] = sum_p x[b][c][p]^2, one workgroup per (image, channel)
+__global__ __launch_bounds__(256) void plane_sumsq_kernel(const float* __restrict__ x, long x_bs, float* __restrict__ out,
+                                                          int C, int HW, int nsq) {
+  __shared__ float red[16];
+  const int b = blockIdx.x / nsq, c = blockIdx.x % nsq;
+  const float* __restrict__ p = x + b * x_bs + (long)c * HW;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) s += p[i] * p[i];
+  const float t = pir_block_sum(s, red);
+  if (threadIdx.x == 0) out[(long)b * nsq + c] = t;
+}
+
 // ------------------------------------------------------------------------------------ pixel (un)shuffle
 // lo side: [B][4C][H][W]; hi side: [B][C][2H][2W].  One thread per hi-side float4 (4 columns).
 template <bool TO_LO>
@@ -289,18 +302,49 @@ __global__ void pixel_shuffle_kernel(const float* __restrict__ src, long s_bs, f
 
 }  // namespace
 
+// register-only kernels for power-of-two widths (stencil_wave.hip); 1000 = shape not served, use the LDS-tiled kernels
+int pir_sw_try_fwd(const float* x, long x_bs, const float* w, int flip, float* y, long y_bs, float* sq_parts, int nsq,
+                   int* nparts, int B, int C, int H, int W, hipStream_t s);
+int pir_sw_try_gate(const float* x, long x_bs, const float* w, float* g, long g_bs, int B, int hid, int H, int W, hipStream_t s);
+int pir_sw_try_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* w, float* dx, long dx_bs,
+                   float* ws, size_t ws_floats, int B, int C, int H, int W, int* parts_out, hipStream_t s);
+size_t pir_sw_bwd_ws_floats(int B, int C, int H);
+
 extern "C" int pir_dwconv3x3(const float* x, long x_bs, const float* w, int flip, float* y, long y_bs,
                              int B, int C, int H, int W, pir_stream_t stream) {
   PIR_CHECK_ARG(x && w && y && B > 0 && C > 0 && H > 0 && W > 0);
+  const int st = pir_sw_try_fwd(x, x_bs, w, flip, y, y_bs, nullptr, 0, nullptr, B, C, H, W, (hipStream_t)stream);
+  if (st != 1000) return st;
   DwArgs a = {};
   a.x = x; a.x_bs = x_bs; a.w = w; a.y = y; a.y_bs = y_bs; a.B = B; a.C = C; a.H = H; a.W = W; a.flip = flip;
   const bool aligned = al16(x) && al16(y) && x_bs % 4 == 0 && y_bs % 4 == 0;
   return launch_dw<MODE_FWD>(a, aligned, (hipStream_t)stream);
 }
 
+extern "C" size_t pir_dwconv3x3_sumsq_floats(int B, int nsq, int H) {
+  if (B <= 0 || nsq <= 0 || H <= 0) return 0;
+  return (size_t)B * pir_cdiv(H, 8 < H ? 8 : H) * nsq;
+}
+
+extern "C" int pir_dwconv3x3_sumsq(const float* x, long x_bs, const float* w, float* y, long y_bs, float* sq_parts,
+                                   size_t sq_floats, int nsq, int* nparts, int B, int C, int H, int W, pir_stream_t stream) {
+  PIR_CHECK_ARG(x && w && y && sq_parts && nparts && B > 0 && C > 0 && H > 0 && W > 0 && nsq > 0 && nsq <= C);
+  if (sq_floats < pir_dwconv3x3_sumsq_floats(B, nsq, H)) return PIR_ENOMEM;
+  int st = pir_sw_try_fwd(x, x_bs, w, 0, y, y_bs, sq_parts, nsq, nparts, B, C, H, W, (hipStream_t)stream);
+  if (st != 1000) return st;
+  st = pir_dwconv3x3(x, x_bs, w, 0, y, y_bs, B, C, H, W, stream);   // LDS-tiled stencil, then one pass over q and k
+  if (st) return st;
+  *nparts = 1;
+  hipLaunchKernelGGL(plane_sumsq_kernel, dim3((unsigned)((long)B * nsq)), dim3(256), 0, (hipStream_t)stream, y, y_bs,
+                     sq_parts, C, H * W, nsq);
+  return pir_launch_status();
+}
+
 extern "C" int pir_dwconv3x3_gate(const float* x, long x_bs, const float* w, float* g, long g_bs,
                                   int B, int hid, int H, int W, pir_stream_t stream) {
   PIR_CHECK_ARG(x && w && g && B > 0 && hid > 0 && H > 0 && W > 0);
+  const int sw = pir_sw_try_gate(x, x_bs, w, g, g_bs, B, hid, H, W, (hipStream_t)stream);
+  if (sw != 1000) return sw;
   DwArgs a = {};
   a.x = x; a.x_bs = x_bs; a.w = w; a.y = g; a.y_bs = g_bs; a.B = B; a.C = hid; a.hid = hid; a.H = H; a.W = W;
   const bool aligned = al16(x) && al16(g) && x_bs % 4 == 0 && g_bs % 4 == 0;
@@ -348,13 +392,20 @@ extern "C" size_t pir_dwconv3x3_bwd_ws_floats(int B, int C, int H, int W) {
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
   DwPlan p4 = dw_plan(H, W, W % 4 == 0, 2), p1 = dw_plan(H, W, false, 2);
   const size_t t4 = (size_t)p4.tiles_c, t1 = (size_t)p1.tiles_c;
-  return (size_t)B * (t4 > t1 ? t4 : t1) * C * 9;
+  const size_t lds = (size_t)B * (t4 > t1 ? t4 : t1) * C * 9, wave = pir_sw_bwd_ws_floats(B, C, H);
+  return lds > wave ? lds : wave;
 }
 
 extern "C" int pir_dwconv3x3_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* w,
                                  float* dx, long dx_bs, float* dw, float* ws, size_t ws_floats,
                                  int B, int C, int H, int W, pir_stream_t stream) {
   PIR_CHECK_ARG(dy && x && w && dx && dw && ws && B > 0 && C > 0 && H > 0 && W > 0);
+  {
+    int wparts = 0;
+    const int sw = pir_sw_try_bwd(dy, dy_bs, x, x_bs, w, dx, dx_bs, ws, ws_floats, B, C, H, W, &wparts, (hipStream_t)stream);
+    if (sw == 0) return pir_reduce_partials(ws, (long)C * 9, wparts, 1.f, 0, dw, (long)C * 9, stream);
+    if (sw != 1000) return sw;
+  }
   DwArgs a = {};
   a.x = x; a.x_bs = x_bs; a.w = w; a.flip = 1; a.y = dx; a.y_bs = dx_bs; a.dz = dy; a.dz_bs = dy_bs; a.ws = ws;
   a.B = B; a.C = C; a.H = H; a.W = W;

@@ -494,8 +494,23 @@ def copy_planes(src, dst, accumulate=False):
                               _stream()), "pir_copy_planes")
 
 
-def mdta_core_forward(qkv: torch.Tensor, temperature: torch.Tensor, heads: int):
-    """From qkv = dw3x3(1x1(x)) to out = softmax(norm(q) norm(k)^T * t) v (net/model.py:121-135)."""
+def dwconv_sumsq_forward(x, w, nsq):
+    """y = dw3x3(x) and, from the same pass, partial sums of squares of the first `nsq` output channels
+    (pir_dwconv3x3_sumsq): returns (y, sumsq [B, nparts, nsq])."""
+    x = _planes(x)
+    b, c, h, wd = x.shape
+    y = torch.empty((b, c, h, wd), dtype=torch.float32, device=x.device)
+    cap = int(lib.pir_dwconv3x3_sumsq_floats(b, nsq, h))
+    sq = torch.empty(cap, dtype=torch.float32, device=x.device)
+    nparts = C.c_int(0)
+    check(lib.pir_dwconv3x3_sumsq(x.data_ptr(), _bs(x), w.data_ptr(), y.data_ptr(), _bs(y), sq.data_ptr(), cap, nsq,
+                                  C.byref(nparts), b, c, h, wd, _stream()), "pir_dwconv3x3_sumsq")
+    return y, sq[: b * nparts.value * nsq].view(b, nparts.value, nsq)
+
+
+def mdta_core_forward(qkv: torch.Tensor, temperature: torch.Tensor, heads: int, sumsq: Optional[torch.Tensor] = None):
+    """From qkv = dw3x3(1x1(x)) to out = softmax(norm(q) norm(k)^T * t) v (net/model.py:121-135).
+    `sumsq` [B, nparts, 2C]: the squared q / k norms if the depthwise kernel already produced them."""
     qkv = _planes(qkv)
     b, c3, h, w = qkv.shape
     c_all = c3 // 3
@@ -503,13 +518,15 @@ def mdta_core_forward(qkv: torch.Tensor, temperature: torch.Tensor, heads: int):
     hw = h * w
     dev = qkv.device
     bs = _bs(qkv)
-    sumsq = torch.empty((b, 2 * c_all), dtype=torch.float32, device=dev)
-    check(lib.pir_row_sumsq(qkv.data_ptr(), bs, sumsq.data_ptr(), b, 2 * c_all, hw, _stream()), "pir_row_sumsq")
+    if sumsq is None:
+        sumsq = torch.empty((b, 1, 2 * c_all), dtype=torch.float32, device=dev)
+        check(lib.pir_row_sumsq(qkv.data_ptr(), bs, sumsq.data_ptr(), b, 2 * c_all, hw, _stream()), "pir_row_sumsq")
+    nparts = sumsq.shape[1]
     gram = torch.empty((b, heads, c, c), dtype=torch.float32, device=dev)
     gemm_nt(qkv, 0, (bs, c * hw, 0), hw, qkv, c_all * hw, (bs, c * hw, 0), hw, gram, 0, (c * c, c, 1),
             c, c, hw, b, heads, 1)
     attn = torch.empty_like(gram)
-    check(lib.pir_mdta_softmax_fwd(gram.data_ptr(), sumsq.data_ptr(), temperature.data_ptr(), attn.data_ptr(),
+    check(lib.pir_mdta_softmax_fwd(gram.data_ptr(), sumsq.data_ptr(), nparts, temperature.data_ptr(), attn.data_ptr(),
                                    b, heads, c, _stream()), "pir_mdta_softmax_fwd")
     out = torch.empty((b, c_all, h, w), dtype=torch.float32, device=dev)
     gemm_nn(attn, (heads * c * c, c * c), c, 1, qkv, 2 * c_all * hw, (bs, c * hw), hw,
@@ -538,7 +555,7 @@ def mdta_core_backward(dout, qkv, temperature, heads, attn, gram, sumsq, dtemp_o
     alpha_q = torch.empty((b, c_all), dtype=torch.float32, device=dev)
     alpha_k = torch.empty_like(alpha_q)
     dtemp_part = torch.empty((b, heads), dtype=torch.float32, device=dev)
-    check(lib.pir_mdta_softmax_bwd(dattn.data_ptr(), attn.data_ptr(), gram.data_ptr(), sumsq.data_ptr(),
+    check(lib.pir_mdta_softmax_bwd(dattn.data_ptr(), attn.data_ptr(), gram.data_ptr(), sumsq.data_ptr(), sumsq.shape[1],
                                    temperature.data_ptr(), dgram.data_ptr(), alpha_q.data_ptr(), alpha_k.data_ptr(),
                                    dtemp_part.data_ptr(), b, heads, c, _stream()), "pir_mdta_softmax_bwd")
     # dq = dG k + alpha_q * q
@@ -823,8 +840,8 @@ class TransformerBlockFn(torch.autograd.Function):
         _require_gpu(x, n1w, n1b, temperature, wqkv, wdw1, wproj, n2w, n2b, win, wdw2, wout)
         xn1, m1, r1 = layernorm_forward(x, n1w, n1b)
         qkv0 = conv1x1_forward(xn1, wqkv)
-        qkv = dwconv_forward(qkv0, wdw1)
-        out, attn, gram, sumsq = mdta_core_forward(qkv, temperature, heads)
+        qkv, sumsq = dwconv_sumsq_forward(qkv0, wdw1, 2 * x.shape[1])   # q / k norms from the stencil's own pass
+        out, attn, gram, sumsq = mdta_core_forward(qkv, temperature, heads, sumsq)
         x1 = conv1x1_forward(out, wproj, residual=x)
         xn2, m2, r2 = layernorm_forward(x1, n2w, n2b)
         h0 = conv1x1_forward(xn2, win)

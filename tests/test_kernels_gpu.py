@@ -131,7 +131,58 @@ def test_dwconv_fwd_bwd(b, c, h, w):
     close(ops.dwconv_wgrad(dy.to(DEV), x.to(DEV), wt.to(DEV)), wr.grad, rtol=5e-5)
 
 
-@pytest.mark.parametrize("b,hid,h,w", [(2, 5, 16, 16), (1, 127, 9, 11), (1, 3, 128, 128)])
+@pytest.mark.parametrize("b,c,h,w", [(2, 6, 16, 16), (3, 9, 64, 64), (2, 5, 128, 128), (1, 3, 40, 256), (2, 12, 33, 32),
+                                     (1, 4, 7, 8), (1, 5, 9, 11), (2, 3, 20, 48)])
+def test_dwconv_sumsq_and_wave_stencils(b, c, h, w):
+    """pir_dwconv3x3_sumsq (stencil + squared L2 norms of the first channels in one pass), the register-only forward /
+    gate / fused-backward stencils on power-of-two widths (several units per wave, idle lanes, ragged heights, bands
+    ending inside the image) and their LDS-tiled fallbacks on other widths, also on channel slices of larger buffers
+    whose batch stride only allows narrower accesses."""
+    from promptir_amd import ops
+
+    nsq = max(1, 2 * c // 3)
+    x, wt, dy = rnd("x", b, c, h, w), rnd("w", c, 1, 3, 3), rnd("dy", b, c, h, w)
+    ref = F.conv2d(x, wt, padding=1, groups=c)
+    y, sq = ops.dwconv_sumsq_forward(x.to(DEV), wt.to(DEV), nsq)
+    close(y, ref)
+    assert sq.shape[0] == b and sq.shape[2] == nsq
+    close(sq.sum(dim=1), (ref[:, :nsq] ** 2).sum(dim=(2, 3)), rtol=2e-5)
+    # slice of a wider buffer: batch stride (c+1)*h*w, first channel skipped
+    big = rnd("big", b, c + 1, h, w)
+    y2, sq2 = ops.dwconv_sumsq_forward(big.to(DEV)[:, 1:], wt.to(DEV), nsq)
+    ref2 = F.conv2d(big[:, 1:], wt, padding=1, groups=c)
+    close(y2, ref2)
+    close(sq2.sum(dim=1), (ref2[:, :nsq] ** 2).sum(dim=(2, 3)), rtol=2e-5)
+    # fused backward (dx + dw) and the flipped-tap forward
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    F.conv2d(xr, wr, padding=1, groups=c).backward(dy)
+    dx, dw = ops.dwconv_backward(dy.to(DEV), x.to(DEV), wt.to(DEV))
+    close(dx, xr.grad)
+    close(dw, wr.grad, rtol=5e-5)
+    close(ops.dwconv_forward(dy.to(DEV), wt.to(DEV), flip=True), xr.grad)
+    if c % 2 == 0:
+        hid = c // 2
+        t = F.conv2d(x, wt, padding=1, groups=c)
+        close(ops.dwconv_gate_forward(x.to(DEV), wt.to(DEV)), F.gelu(t[:, :hid]) * t[:, hid:])
+
+
+def test_fast_gelu_of_the_backward_kernels_vs_fp64():
+    """The GDFN backward evaluates gelu / gelu' with a branch-free erf (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7);
+    check the resulting gradient against float64 autograd over a wide range of pre-activations (incl. the tails)."""
+    from promptir_amd import ops
+
+    b, hid, h, w = 1, 4, 64, 64
+    x = rnd("x", b, 2 * hid, h, w) * 6.0                       # depthwise outputs up to ~ +-20
+    wt, dg = rnd("w", 2 * hid, 1, 3, 3), rnd("dg", b, hid, h, w)
+    xr, wr = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    t = F.conv2d(xr, wr, padding=1, groups=2 * hid)
+    (0.5 * t[:, :hid] * (1 + torch.erf(t[:, :hid] / 2 ** 0.5)) * t[:, hid:]).backward(dg.double())
+    dx, dw = ops.gdfn_dwconv_backward(x.to(DEV), wt.to(DEV), dg.to(DEV))
+    assert float((dx.cpu().double() - xr.grad).abs().max()) <= 2e-5 * float(xr.grad.abs().max())
+    assert float((dw.cpu().double() - wr.grad).abs().max()) <= 5e-5 * float(wr.grad.abs().max())
+
+
+@pytest.mark.parametrize("b,hid,h,w", [(2, 5, 16, 16), (1, 127, 9, 11), (1, 3, 128, 128), (2, 33, 64, 64), (3, 7, 32, 32)])
 def test_dwconv_gate(b, hid, h, w):
     from promptir_amd import ops
 

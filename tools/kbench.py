@@ -90,6 +90,8 @@ def bench_dw(B):
         y = torch.empty_like(x)
         t = timeit(lambda: ops.dwconv_forward(x, w, out=y))
         print(f"{name:18s} dw fwd   C={3*C:4d}: {t*1e6:8.1f} us {8.0*x.numel()/t/1e9:7.0f} GB/s")
+        t = timeit(lambda: ops.dwconv_sumsq_forward(x, w, 2 * C))
+        print(f"{name:18s} dw fwd+sumsq C={3*C:4d}: {t*1e6:8.1f} us {8.0*x.numel()/t/1e9:7.0f} GB/s")
         t = timeit(lambda: ops.dwconv_wgrad(y, x, w))
         print(f"{name:18s} dw wgrad C={3*C:4d}: {t*1e6:8.1f} us {8.0*x.numel()/t/1e9:7.0f} GB/s")
         x2, w2 = r(B, 2 * hid, S, S), r(2 * hid, 1, 3, 3)
