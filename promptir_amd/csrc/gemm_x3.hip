@@ -16,6 +16,9 @@
 #ifndef X3_MFMA_PRIO
 #define X3_MFMA_PRIO 0   // experiment knob: > 0 raises the wave priority around the MFMA cluster, < 0 raises it everywhere else
 #endif
+#ifndef X3_OCC4
+#define X3_OCC4 1   // 64 x 128 tile with pre-split weights: four workgroups per CU (128 registers, 37.6 KB of LDS)
+#endif
 #ifndef X3_VMEM_FILL
 #define X3_VMEM_FILL 1   // issue the prefetch loads one per MFMA inside the main loop
 #endif
@@ -53,7 +56,7 @@ struct X3Conv { int H, W, ksteps; unsigned magic_ks, magic_w; };
 // waves_per_eu: the 128-column tiles (<= 50 KB of LDS) fit three workgroups per CU once the compiler is told to
 // stay within 168 registers (it then also keeps the accumulators in VGPRs); the 256-column tiles run two.
 template <int TM, int TN, int WM, int WN, bool A_MFAST, bool A_PRE, bool CONV = false>
-__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(((WM == 2 && WN == 2 && (A_PRE || TM * TN <= 2)) || (TM == 3 && TN == 1 && A_PRE)) ? 3 : 2)))
+__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu((WM == 2 && WN == 2 && TM == 1 && A_PRE && X3_OCC4) ? 4 : ((WM == 2 && WN == 2 && (A_PRE || TM * TN <= 2)) || (TM == 3 && TN == 1 && A_PRE)) ? 3 : 2)))
 void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, T = WM * WN * 64;
   constexpr int AKS = BM + 4;              // 16-byte units between the two k-groups of A (+4: bank shift)
@@ -455,12 +458,13 @@ int pir_nn_x3_plan(const pir_gemm_nn_t* a, int cfg) {
   // row and stage) wins at the high-resolution levels even with up to ~13 % more padded rows.
   if (M <= 32) return 1214;
   if (M <= 64) return g.K <= 64 ? 1222 : 2214;
-  // 96 x 128 (three workgroups per CU) for the GDFN project_in pair at the 96-channel levels: -6 ... -11 % there,
-  // neutral or worse for the other full-resolution shapes (tools/cfg7.py)
-  if (g.A3 && ((M >= 384 && g.K <= 128 && g.N >= 4096) || (g.K >= 384 && M == 96 && g.N >= 16384)) &&
-      pir_cdiv(M, 96) * 96 * 100 <= pir_cdiv(M, 128) * 128 * 113)
-    return 3114;
   const long pad96 = pir_cdiv(M, 96) * 96, pad128 = pir_cdiv(M, 128) * 128;
+  // Short k loops on long pixel rows (forward / input gradient of the 1x1 convolutions at the 128^2 and 64^2 levels,
+  // HBM-bound): when 128-row tiles waste no more rows than 96-row tiles (M = 254, 255, 510), the 128 x 128 tile
+  // (three workgroups per CU) is 5-11 % faster than 96 x 128 / 96 x 256 (tools/cfg_ab.py, round 2)
+  if (g.A3 && g.K <= 128 && g.N >= 4096 && M >= 192 && pad128 <= pad96) return 2222;
+  // 96 x 128 (three workgroups per CU) for the project_in input gradient at the 96-channel full-resolution levels
+  if (g.A3 && g.K >= 384 && M == 96 && g.N >= 16384) return 3114;
   const bool use96 = g.N >= 1024 ? pad96 * 100 <= pad128 * 113 : pad96 < pad128;
   const long blocks = use96 ? pir_cdiv(M, 96) * pir_cdiv(g.N, 256) * batch : pir_cdiv(M, 128) * pir_cdiv(g.N, 128) * batch;
   if (blocks < 2L * PIR_NUM_CU && pir_cdiv(M, 64) * 64 <= pad128) return 1222;

@@ -147,9 +147,10 @@ def test_checkpoint_interchange_with_the_lightning_layout():
 
 
 def test_gemm_plan_reaches_the_tuned_tiles_for_config3_shapes():
-    """BASELINE config 3 (128x128 patches): the GDFN project_in pair of the 96-channel levels (dec1 / refinement) was
-    tuned onto the 96 x 128 tile (gemm_x3.hip, pir_nn_x3_plan).  Pin that those exact shapes select it; the GPU
-    parity of the same shapes is tests/test_kernels_gpu.py::test_conv1x1_config3_shapes."""
+    """BASELINE config 3 (128x128 patches): the GDFN project_in pair of the 96-channel levels (dec1 / refinement) runs
+    on tiles tuned for it (gemm_x3.hip, pir_nn_x3_plan: 128 x 128 forward, 96 x 128 input gradient).  Pin that those
+    exact shapes select them; the GPU parity of the same shapes is
+    tests/test_kernels_gpu.py::test_conv1x1_config3_shapes."""
     from promptir_amd import _lib
 
     def plan(M, K, N, batch, presplit=True):
@@ -158,9 +159,10 @@ def test_gemm_plan_reaches_the_tuned_tiles_for_config3_shapes():
         g.A3 = 256 if presplit else None
         return _lib.lib.pir_gemm_nn_plan(ctypes.byref(g))
 
-    assert plan(510, 96, 16384, 32) == 3114      # project_in forward, dec1 / refinement
-    assert plan(96, 510, 16384, 32) == 3114      # its input gradient (M = 96, K = 510, N = 16384)
-    assert plan(510, 96, 4096, 32) == 3114       # level 2 forward
+    assert plan(510, 96, 16384, 32) == 2222      # project_in forward, dec1 / refinement: 128 x 128 (M pads to 512)
+    assert plan(96, 510, 16384, 32) == 3114      # its input gradient (M = 96, K = 510, N = 16384): 96 x 128
+    assert plan(510, 96, 4096, 32) == 2222       # level 2 forward
+    assert plan(255, 96, 16384, 32) == 2222      # project_out input gradient
     assert plan(96, 510, 16384, 2) == 3114       # the test-sized batch takes the same branch
     assert plan(288, 96, 16384, 32) == 3214      # qkv: 96 x 256
     assert plan(48, 48, 16384, 32) == 1222
