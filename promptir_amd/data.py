@@ -28,9 +28,11 @@ def _stream_key(name: str, seed: int) -> int:
     return W.fnv1a64(name) ^ ((seed * _GOLDEN) & 0xFFFFFFFFFFFFFFFF)
 
 
-def degrade_gaussian_gpu(clean: torch.Tensor, sigmas: Sequence[float], seed: int = 0) -> torch.Tensor:
+def degrade_gaussian_gpu(clean: torch.Tensor, sigmas: Sequence[float], seed: int = 0,
+                         stream_seeds: Sequence[int] = None) -> torch.Tensor:
     """uint8-domain noise on the device; image i uses the host streams of `weights.synthetic_pair`
-    (seed + 1000*(i+1)), so results equal weights.degrade_gaussian up to libm rounding of log/cos."""
+    (seed + 1000*(i+1), or `stream_seeds[i]` when given), so results equal weights.degrade_gaussian up to libm
+    rounding of log/cos."""
     from .ops import _require_gpu, _stream, check, lib
 
     _require_gpu(clean)
@@ -39,7 +41,7 @@ def degrade_gaussian_gpu(clean: torch.Tensor, sigmas: Sequence[float], seed: int
     per = clean[0].numel()
     keys = []
     for i in range(b):
-        s = seed + 1000 * (i + 1)
+        s = seed + 1000 * (i + 1) if stream_seeds is None else int(stream_seeds[i])
         keys += [_stream_key("noise#bm1", s), _stream_key("noise#bm2", s)]
     keys_t = torch.tensor(np.array(keys, dtype=np.uint64).view(np.int64), device=clean.device)
     sig = torch.tensor(list(sigmas), dtype=torch.float32, device=clean.device)
@@ -126,3 +128,65 @@ def shard_indices(length: int, rank: int, world: int, epoch: int, seed: int = 0)
     total = (length + world - 1) // world * world
     order += order[: total - length]
     return order[rank:total:world]
+
+
+class CleanPatchSet(torch.utils.data.Dataset):
+    """Clean 8-bit patches only (what the host side of the GPU degradation path reads): item = (de_id, clean, noise seed).
+    The degradation (uint8-domain Gaussian noise, utils/degradation_utils.py:21-27) then runs on the device
+    (`degrade_gaussian_gpu`) with the same generator as the host path, so both pipelines produce the same batches."""
+
+    def __init__(self, length: int, patch_size: int = 128, de_types: Sequence[int] = (0, 1, 2), seed: int = 0):
+        self.length, self.patch, self.de_types, self.seed = length, patch_size, list(de_types), seed
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, idx):
+        de_id = self.de_types[idx % len(self.de_types)]
+        clean = W.synthetic_clean(1, self.patch, self.patch, self.seed + idx)
+        clean = np.floor(clean * 255.0).astype(np.float32) / np.float32(255.0)
+        return de_id, torch.from_numpy(clean[0]), self.seed + idx
+
+
+class DevicePrefetcher:
+    """Iterates (degraded, clean) device batches one step ahead: the host -> device copies of batch k+1 run on a side
+    stream (from pinned memory) while step k computes; replaces DataLoader(pin_memory=True) + Lightning's batch
+    transfer (reference train.py:336).  `gpu_degrade`: the loader yields (de_id, clean, seed) and the noise is added
+    on the device."""
+
+    def __init__(self, loader, device, gpu_degrade: bool = False):
+        self.loader, self.device, self.gpu_degrade = loader, device, gpu_degrade
+        self.stream = torch.cuda.Stream(device)
+
+    def _stage(self, item):
+        with torch.cuda.stream(self.stream):
+            if self.gpu_degrade:
+                de_ids, clean, seeds = item
+                clean = clean.to(self.device, non_blocking=True)
+                sig = [SIGMA_OF_DE_ID[int(d)] for d in de_ids]
+                # the generator stream of sample i is the one synthetic_pair(1, ..., seed=s_i) uses: s_i + 1000
+                degrad = degrade_gaussian_gpu(clean, sig, stream_seeds=[int(v) + 1000 for v in seeds])
+            else:
+                _, degrad, clean = item
+                degrad = degrad.to(self.device, non_blocking=True)
+                clean = clean.to(self.device, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(self.stream)
+        return degrad, clean, ready
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            nxt = self._stage(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            degrad, clean, ready = nxt
+            try:
+                nxt = self._stage(next(it))      # enqueue the next copies before handing out the current batch
+            except StopIteration:
+                nxt = None
+            torch.cuda.current_stream(self.device).wait_event(ready)
+            degrad.record_stream(torch.cuda.current_stream(self.device))
+            clean.record_stream(torch.cuda.current_stream(self.device))
+            yield degrad, clean

@@ -508,10 +508,9 @@ def dwconv_sumsq_forward(x, w, nsq):
     return y, sq[: b * nparts.value * nsq].view(b, nparts.value, nsq)
 
 
-def mdta_core_forward(qkv: torch.Tensor, temperature: torch.Tensor, heads: int, sumsq: Optional[torch.Tensor] = None):
-    """From qkv = dw3x3(1x1(x)) to out = softmax(norm(q) norm(k)^T * t) v (net/model.py:121-135).
+def mdta_attn_forward(qkv: torch.Tensor, temperature: torch.Tensor, heads: int, sumsq: Optional[torch.Tensor] = None):
+    """attn = softmax(norm(q) norm(k)^T * temperature) per (image, head) (net/model.py:127-131).
     `sumsq` [B, nparts, 2C]: the squared q / k norms if the depthwise kernel already produced them."""
-    qkv = _planes(qkv)
     b, c3, h, w = qkv.shape
     c_all = c3 // 3
     c = c_all // heads
@@ -528,7 +527,48 @@ def mdta_core_forward(qkv: torch.Tensor, temperature: torch.Tensor, heads: int, 
     attn = torch.empty_like(gram)
     check(lib.pir_mdta_softmax_fwd(gram.data_ptr(), sumsq.data_ptr(), nparts, temperature.data_ptr(), attn.data_ptr(),
                                    b, heads, c, _stream()), "pir_mdta_softmax_fwd")
-    out = torch.empty((b, c_all, h, w), dtype=torch.float32, device=dev)
+    return attn, gram, sumsq
+
+
+def mdta_attn_backward(dattn, qkv, temperature, heads, attn, gram, sumsq, dqkv, dtemp_out=None):
+    """From dattn to dq, dk (written into the q / k thirds of `dqkv`) and dtemperature: backward through softmax,
+    temperature and the two L2 normalisations (net/model.py:127-131)."""
+    b, c3, h, w = qkv.shape
+    c_all = c3 // 3
+    c = c_all // heads
+    hw = h * w
+    dev = qkv.device
+    bs, qbs = _bs(qkv), c3 * hw
+    dgram = torch.empty_like(attn)
+    alpha_q = torch.empty((b, c_all), dtype=torch.float32, device=dev)
+    alpha_k = torch.empty_like(alpha_q)
+    dtemp_part = torch.empty((b, heads), dtype=torch.float32, device=dev)
+    check(lib.pir_mdta_softmax_bwd(dattn.data_ptr(), attn.data_ptr(), gram.data_ptr(), sumsq.data_ptr(), sumsq.shape[1],
+                                   temperature.data_ptr(), dgram.data_ptr(), alpha_q.data_ptr(), alpha_k.data_ptr(),
+                                   dtemp_part.data_ptr(), b, heads, c, _stream()), "pir_mdta_softmax_bwd")
+    # dq = dG k + alpha_q * q
+    gemm_nn(dgram, (heads * c * c, c * c), c, 1, qkv, c_all * hw, (bs, c * hw), hw,
+            dqkv, 0, (qbs, c * hw), hw, c, c, hw, b, heads,
+            R=qkv, r_off=0, r_batch=(bs, c * hw), ldr=hw, rowscale=alpha_q, rs_batch=(c_all, c))
+    # dk = dG^T q + alpha_k * k
+    gemm_nn(dgram, (heads * c * c, c * c), 1, c, qkv, 0, (bs, c * hw), hw,
+            dqkv, c_all * hw, (qbs, c * hw), hw, c, c, hw, b, heads,
+            R=qkv, r_off=c_all * hw, r_batch=(bs, c * hw), ldr=hw, rowscale=alpha_k, rs_batch=(c_all, c))
+    dtemp = _grad_out(temperature, dtemp_out)
+    reduce_partials(dtemp_part, heads, b, dtemp, heads)
+    return dtemp
+
+
+def mdta_core_forward(qkv: torch.Tensor, temperature: torch.Tensor, heads: int, sumsq: Optional[torch.Tensor] = None):
+    """From qkv = dw3x3(1x1(x)) to out = softmax(norm(q) norm(k)^T * t) v (net/model.py:121-135)."""
+    qkv = _planes(qkv)
+    b, c3, h, w = qkv.shape
+    c_all = c3 // 3
+    c = c_all // heads
+    hw = h * w
+    bs = _bs(qkv)
+    attn, gram, sumsq = mdta_attn_forward(qkv, temperature, heads, sumsq)
+    out = torch.empty((b, c_all, h, w), dtype=torch.float32, device=qkv.device)
     gemm_nn(attn, (heads * c * c, c * c), c, 1, qkv, 2 * c_all * hw, (bs, c * hw), hw,
             out, 0, (c_all * hw, c * hw), hw, c, c, hw, b, heads)
     return out, attn, gram, sumsq
@@ -551,24 +591,54 @@ def mdta_core_backward(dout, qkv, temperature, heads, attn, gram, sumsq, dtemp_o
     # dv = A^T dout :  A'(m=j, k=i) = attn[i*c + j]
     gemm_nn(attn, (heads * c * c, c * c), 1, c, dout, 0, (dbs, c * hw), hw,
             dqkv, 2 * c_all * hw, (qbs, c * hw), hw, c, c, hw, b, heads)
-    dgram = torch.empty_like(attn)
-    alpha_q = torch.empty((b, c_all), dtype=torch.float32, device=dev)
-    alpha_k = torch.empty_like(alpha_q)
-    dtemp_part = torch.empty((b, heads), dtype=torch.float32, device=dev)
-    check(lib.pir_mdta_softmax_bwd(dattn.data_ptr(), attn.data_ptr(), gram.data_ptr(), sumsq.data_ptr(), sumsq.shape[1],
-                                   temperature.data_ptr(), dgram.data_ptr(), alpha_q.data_ptr(), alpha_k.data_ptr(),
-                                   dtemp_part.data_ptr(), b, heads, c, _stream()), "pir_mdta_softmax_bwd")
-    # dq = dG k + alpha_q * q
-    gemm_nn(dgram, (heads * c * c, c * c), c, 1, qkv, c_all * hw, (bs, c * hw), hw,
-            dqkv, 0, (qbs, c * hw), hw, c, c, hw, b, heads,
-            R=qkv, r_off=0, r_batch=(bs, c * hw), ldr=hw, rowscale=alpha_q, rs_batch=(c_all, c))
-    # dk = dG^T q + alpha_k * k
-    gemm_nn(dgram, (heads * c * c, c * c), 1, c, qkv, 0, (bs, c * hw), hw,
-            dqkv, c_all * hw, (qbs, c * hw), hw, c, c, hw, b, heads,
-            R=qkv, r_off=c_all * hw, r_batch=(bs, c * hw), ldr=hw, rowscale=alpha_k, rs_batch=(c_all, c))
-    dtemp = _grad_out(temperature, dtemp_out)
-    reduce_partials(dtemp_part, heads, b, dtemp, heads)
+    dtemp = mdta_attn_backward(dattn, qkv, temperature, heads, attn, gram, sumsq, dqkv, dtemp_out)
     return dqkv, dtemp
+
+
+# ---- `attn @ v` folded into project_out (net/model.py:133-137): per image
+#        x1 = W_proj (blockdiag_h(attn_h) v) + x = W_eff v + x,   W_eff[:, h-block] = W_proj[:, h-block] attn_h   (C x C)
+#      One C x C x HW GEMM instead of two per block in the forward, and in the backward
+#        dv = W_eff^T dx1,  dW_eff = dx1 v^T   (two C x C x HW GEMMs instead of four: no project_out input / weight
+#        gradient over the pixels, no dattn = dout v^T, no dv = attn^T dout), followed by C x C x c sized products
+#        dW_proj[:, h-block] = sum_b dW_eff_b[:, h-block] attn_{b,h}^T,   dattn_{b,h} = W_proj[:, h-block]^T dW_eff_b[:, h-block].
+#      `out` is never materialised (C planes less to write, read and keep for the backward).
+def mdta_fold_forward(qkv, attn, wproj, x_res, heads):
+    b, c3, h, w = qkv.shape
+    C = c3 // 3
+    c = C // heads
+    hw = h * w
+    bs = _bs(qkv)
+    weff = torch.empty((b, C, C), dtype=torch.float32, device=qkv.device)
+    # W_eff[b][:, h*c:(h+1)*c] = W_proj[:, h*c:(h+1)*c] @ attn[b, h]        (M = C, K = c, N = c per (image, head))
+    gemm_nn(wproj, (0, c), C, 1, attn, 0, (heads * c * c, c * c), c, weff, 0, (C * C, c), C, C, c, c, b, heads)
+    x1 = torch.empty((b, C, h, w), dtype=torch.float32, device=qkv.device)
+    x_res = _planes(x_res)
+    gemm_nn(weff, (C * C, 0), C, 1, qkv, 2 * C * hw, (bs, 0), hw, x1, 0, (C * hw, 0), hw, C, C, hw, b, 1,
+            R=x_res, r_batch=(_bs(x_res), 0), ldr=hw)
+    return x1, weff
+
+
+def mdta_fold_backward(dx1, qkv, attn, weff, wproj, heads, dqkv, dwproj_out=None):
+    """Writes dv into the v third of `dqkv`, returns (dattn, dW_proj)."""
+    dx1 = _planes(dx1)
+    b, c3, h, w = qkv.shape
+    C = c3 // 3
+    c = C // heads
+    hw = h * w
+    dev = qkv.device
+    bs, dbs, qbs = _bs(qkv), _bs(dx1), c3 * hw
+    # dv = W_eff^T dx1
+    gemm_nn(weff, (C * C, 0), 1, C, dx1, 0, (dbs, 0), hw, dqkv, 2 * C * hw, (qbs, 0), hw, C, C, hw, b, 1)
+    # dW_eff[b] = dx1[b] v[b]^T
+    dweff = torch.empty((b, C, C), dtype=torch.float32, device=dev)
+    gemm_nt(dx1, 0, (dbs, 0, 0), hw, qkv, 2 * C * hw, (bs, 0, 0), hw, dweff, 0, (C * C, C, 1), C, C, hw, b, 1, 1)
+    # dW_proj[:, h-block] = sum_b dW_eff[b][:, h-block] attn[b, h]^T      (contraction over j, then over the batch)
+    dwproj = _grad_out(wproj, dwproj_out)
+    gemm_nt(dweff, 0, (0, c, C * C), C, attn, 0, (0, c * c, heads * c * c), c, dwproj, 0, (c, C, 1), C, c, c, 1, heads, b)
+    # dattn[b, h] = W_proj[:, h-block]^T dW_eff[b][:, h-block]            (M = c, K = C, N = c)
+    dattn = torch.empty_like(attn)
+    gemm_nn(wproj, (0, c), 1, C, dweff, 0, (C * C, c), C, dattn, 0, (heads * c * c, c * c), c, c, C, c, b, heads)
+    return dattn, dwproj
 
 
 def pixel_unshuffle(x):
@@ -766,6 +836,8 @@ class MdtaCoreFn(torch.autograd.Function):
 
 
 USE_SIDE_STREAM = _os.environ.get("PIR_SIDE_STREAM", "1") != "0"   # default for callers outside a trainer
+MDTA_FOLD = _os.environ.get("PIR_MDTA_FOLD", "1") != "0"             # fold attn @ v into project_out (TransformerBlockFn)
+MDTA_FOLD_MIN_HW = int(_os.environ.get("PIR_MDTA_FOLD_MIN_HW", "0")) # ... for planes of at least this many pixels
 _SIDE_STREAMS = {}
 _SIDE_OVERRIDE = []   # innermost `side_streams(...)` scope wins over the module default
 
@@ -841,13 +913,23 @@ class TransformerBlockFn(torch.autograd.Function):
         xn1, m1, r1 = layernorm_forward(x, n1w, n1b)
         qkv0 = conv1x1_forward(xn1, wqkv)
         qkv, sumsq = dwconv_sumsq_forward(qkv0, wdw1, 2 * x.shape[1])   # q / k norms from the stencil's own pass
-        out, attn, gram, sumsq = mdta_core_forward(qkv, temperature, heads, sumsq)
-        x1 = conv1x1_forward(out, wproj, residual=x)
+        attn, gram, sumsq = mdta_attn_forward(qkv, temperature, heads, sumsq)
+        fold = MDTA_FOLD and x.shape[2] * x.shape[3] >= MDTA_FOLD_MIN_HW
+        if fold:     # attn @ v folded into project_out: one C x C x HW GEMM, `out` never exists
+            x1, out = mdta_fold_forward(qkv, attn, wproj, x, heads)     # `out` slot keeps W_eff [B, C, C]
+        else:
+            out = torch.empty_like(x)
+            b_, c_all, hw_ = x.shape[0], x.shape[1], x.shape[2] * x.shape[3]
+            c_ = c_all // heads
+            gemm_nn(attn, (heads * c_ * c_, c_ * c_), c_, 1, qkv, 2 * c_all * hw_, (_bs(qkv), c_ * hw_), hw_,
+                    out, 0, (c_all * hw_, c_ * hw_), hw_, c_, c_, hw_, b_, heads)
+            x1 = conv1x1_forward(out, wproj, residual=x)
         xn2, m2, r2 = layernorm_forward(x1, n2w, n2b)
         h0 = conv1x1_forward(xn2, win)
         g = dwconv_gate_forward(h0, wdw2)
         x2 = conv1x1_forward(g, wout, residual=x1)
         ctx.heads = heads
+        ctx.fold = fold
         ctx.with_bias = (n1b is not None, n2b is not None)
         ctx.sinks = tuple(_sink(p) for p in (n1w, n1b, temperature, wqkv, wdw1, wproj, n2w, n2b, win, wdw2, wout))
         ctx.save_for_backward(x, n1w, temperature, wqkv, wdw1, wproj, n2w, win, wdw2, wout,
@@ -873,10 +955,15 @@ class TransformerBlockFn(torch.autograd.Function):
         dx1, d_n2w, d_n2b = layernorm_backward(dxn2, x1, n2w, ctx.with_bias[1], m2, r2, s_n2w, s_n2b, dres=dx2)
         del dxn2
         # ---- MDTA branch
-        dout = conv1x1_dgrad(dx1, wproj)
-        d_wproj = side.wgrad(dx1, out, wproj, s_proj)
-        dqkv, d_temp = mdta_core_backward(dout, qkv, temperature, ctx.heads, attn, gram, sumsq, s_t)
-        del dout
+        if ctx.fold:
+            dqkv = torch.empty_like(qkv)
+            dattn, d_wproj = mdta_fold_backward(dx1, qkv, attn, out, wproj, ctx.heads, dqkv, s_proj)   # out = W_eff
+            d_temp = mdta_attn_backward(dattn, qkv, temperature, ctx.heads, attn, gram, sumsq, dqkv, s_t)
+        else:
+            dout = conv1x1_dgrad(dx1, wproj)
+            d_wproj = side.wgrad(dx1, out, wproj, s_proj)
+            dqkv, d_temp = mdta_core_backward(dout, qkv, temperature, ctx.heads, attn, gram, sumsq, s_t)
+            del dout
         dqkv0, d_wdw1 = dwconv_backward(dqkv, qkv0, wdw1, s_dw1)
         del dqkv
         dxn1 = conv1x1_dgrad(dqkv0, wqkv)

@@ -89,3 +89,23 @@ def test_train_cli_under_an_rccl_process_group(tmp_path):
                 "LOCAL_RANK": "0"})
     assert out.returncode == 0, out.stderr[-3000:]
     assert "process group nccl" in out.stdout
+
+
+def test_gpu_degradation_pipeline_equals_the_host_pipeline():
+    """train.py's default input path (CleanPatchSet -> DataLoader -> DevicePrefetcher with pir_degrade_gaussian on a side
+    stream) yields the batches of the host path (SyntheticTrainSet, utils/degradation_utils.py:21-27 semantics)."""
+    from promptir_amd import data as D
+
+    dev = torch.device("cuda:0")
+    idx = [5, 0, 7, 2, 3, 9]
+    host = D.SyntheticTrainSet(12, 64)
+    loader = torch.utils.data.DataLoader(D.CleanPatchSet(12, 64), batch_size=3, sampler=idx, drop_last=True, num_workers=2,
+                                         pin_memory=True)
+    got = list(D.DevicePrefetcher(loader, dev, gpu_degrade=True))
+    assert len(got) == 2
+    for k, (deg, clean) in enumerate(got):
+        ref_deg = torch.stack([host[i][1] for i in idx[3 * k:3 * k + 3]])
+        ref_clean = torch.stack([host[i][2] for i in idx[3 * k:3 * k + 3]])
+        assert torch.equal(clean.cpu(), ref_clean)
+        diff = (deg.cpu() - ref_deg).abs()
+        assert float(diff.max()) <= 1.0 / 255 + 1e-7 and float((diff > 0).float().mean()) <= 1e-4

@@ -37,6 +37,8 @@ def parse():
     p.add_argument('--resume', type=str, default=None, help='checkpoint to resume from')
     p.add_argument('--max_steps', type=int, default=0, help='stop after this many optimiser steps (0 = no limit)')
     p.add_argument('--start_epoch', type=int, default=None)
+    p.add_argument('--gpu_degrade', type=int, default=1,
+                   help='synthetic data: add the uint8-domain noise on the device (pir_degrade_gaussian) instead of on the host')
     return p.parse_args()
 
 
@@ -46,6 +48,7 @@ def main():
         raise SystemExit("only --model promptir is built (SURVEY §2: sibling networks are out of scope)")
     from net.model import PromptIR
     from promptir_amd import data as D
+    from promptir_amd import ops
     from promptir_amd.train import (DataParallelTrainer, init_distributed, load_checkpoint_file, load_lightning_checkpoint,
                                     lightning_epoch_lr)
 
@@ -54,8 +57,12 @@ def main():
         raise SystemExit("train.py needs a ROCm device (no CPU fallback)")
     device = torch.device("cuda", local)
     de_ids = [i for i, n in enumerate(['denoise_15', 'denoise_25', 'denoise_50']) if n in opt.de_type]
+    gpu_degrade = False
     if os.path.isdir(opt.denoise_dir) and not opt.synthetic:
         dataset = D.DenoiseFolderTrainSet(opt.denoise_dir, opt.patch_size, de_ids or [0, 1, 2])
+    elif opt.gpu_degrade:
+        dataset = D.CleanPatchSet(opt.synthetic or 64 * opt.batch_size * world, opt.patch_size, de_ids or [0, 1, 2])
+        gpu_degrade = True
     else:
         dataset = D.SyntheticTrainSet(opt.synthetic or 64 * opt.batch_size * world, opt.patch_size, de_ids or [0, 1, 2])
     if rank == 0:
@@ -81,18 +88,22 @@ def main():
     for epoch in range(start_epoch, opt.epochs):
         lr = lightning_epoch_lr(epoch)                    # utils/schedulers.py:332-346 via train.py:48-50
         idx = D.shard_indices(len(dataset), rank, world, epoch)
-        idx = idx[: len(idx) // opt.batch_size * opt.batch_size]   # drop_last=True (train.py:336)
-        t0, running, nb = time.time(), 0.0, 0
-        for s in range(0, len(idx), opt.batch_size):
-            items = [dataset[i] for i in idx[s:s + opt.batch_size]]
-            degrad = torch.stack([it[1] for it in items]).to(device, non_blocking=True)
-            clean = torch.stack([it[2] for it in items]).to(device, non_blocking=True)
+        # DataLoader(batch_size, drop_last=True, num_workers, pin_memory=True) as reference train.py:336, with the
+        # rank's DistributedSampler-style shard as its sampler; the next batch is copied (and degraded) on a side
+        # stream while the current step runs, and the logged loss is accumulated on the device: no host sync per step.
+        loader = torch.utils.data.DataLoader(dataset, batch_size=opt.batch_size, sampler=idx, drop_last=True,
+                                             num_workers=min(opt.num_workers, os.cpu_count() or 1), pin_memory=True,
+                                             persistent_workers=False)
+        t0, nb = time.time(), 0
+        running = torch.zeros((), dtype=torch.float32, device=device)
+        for degrad, clean in D.DevicePrefetcher(loader, device, gpu_degrade):
             loss = trainer.train_step(degrad, clean, lr=lr)
-            running += float(loss)
+            ops.add_(running, loss)
             nb += 1
             steps += 1
             if opt.max_steps and steps >= opt.max_steps:
                 break
+        running = float(running)      # the epoch's only device -> host synchronisation
         if rank == 0:
             dt = time.time() - t0
             print(f"[train] epoch {epoch} lr {lr:.3e} train_loss {running / max(nb, 1):.5f} "
