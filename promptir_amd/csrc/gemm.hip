@@ -854,6 +854,7 @@ int launch_nt(NTParams& p, size_t ws_floats, int tap_sign, long g_st, hipStream_
 
 int pir_gdfn_wave_tune(int knob, int value);   // gdfn_bwd.hip
 int pir_stencil_wave_tune(int knob, int value);   // stencil_wave.hip
+int pir_ln_tune(int knob, int value);             // norm.hip
 
 extern "C" int pir_tune_set(int knob, int value) {
   switch (knob) {
@@ -864,6 +865,7 @@ extern "C" int pir_tune_set(int knob, int value) {
     case 4: g_nt_x3 = value; return PIR_OK;
     case 6: case 7: return pir_gdfn_wave_tune(knob, value);
     case 8: case 9: case 10: return pir_stencil_wave_tune(knob, value);
+    case 13: return pir_ln_tune(knob, value);
     default: return PIR_EINVAL;
   }
 }

@@ -272,9 +272,155 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(const float* __restrict
   if (threadIdx.x == 0) out[(long)b * C + c] = t * scale;
 }
 
+int g_ln_small = 1;   // pir_tune_set knob 13 (development A/B)
+
+// ---------------------------------------------------------------------------------------------------------------
+// Low-resolution levels (16 x 16 and 32 x 32 planes, 192 ... 704 channels): with 64 pixels per workgroup a batch of
+// 8 images gives 32 ... 128 workgroups of up to 1024 threads - half the chip idle and every wave walking 24+ strided
+// channels.  Here a workgroup owns 16 pixels: a wave = 16 pixels x 4 channel slots, so four times as many
+// workgroups, each lane holding <= 12 channels; per-pixel sums go over the slots by shuffles and over the waves
+// through LDS, per-channel sums (dweight / dbias) over the 16 pixel lanes by shuffles, one partial row per workgroup.
+constexpr int LS_PIX = 16, LS_SLOTS = 64 / LS_PIX;
+
+__device__ __forceinline__ float ls_sum_slots(float v) {    // over the 4 channel slots of a pixel (lanes p, p+16, p+32, p+48)
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float ls_sum_pixels(float v) {   // over the 16 pixel lanes of a slot
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <int NREG, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void ln_fwd_small_kernel(
+    const float* __restrict__ x, long x_bs, const float* __restrict__ weight, const float* __restrict__ bias,
+    float* __restrict__ y, long y_bs, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+    int C, int HW, int tiles) {
+  __shared__ float red[2][WAVES][LS_PIX];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int px = lane & (LS_PIX - 1), slot = lane / LS_PIX;
+  const int b = blockIdx.x / tiles, p = (blockIdx.x % tiles) * LS_PIX + px;
+  const bool ok = p < HW;
+  const int c0 = wid * LS_SLOTS + slot;
+  constexpr int CSTEP = WAVES * LS_SLOTS;
+  const float* xb = x + b * x_bs + (ok ? p : HW - 1);
+  float v[NREG];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NREG; ++i) {
+    const int c = c0 + i * CSTEP;
+    v[i] = c < C ? xb[(long)c * HW] : 0.f;
+    s += v[i];
+  }
+  s = ls_sum_slots(s);
+  if (slot == 0) red[0][wid][px] = s;
+  __syncthreads();
+  float tsum = 0.f;
+#pragma unroll
+  for (int w = 0; w < WAVES; ++w) tsum += red[0][w][px];
+  const float mu = tsum / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NREG; ++i) {
+    const float d = (c0 + i * CSTEP < C) ? v[i] - mu : 0.f;
+    ss += d * d;
+  }
+  ss = ls_sum_slots(ss);
+  if (slot == 0) red[1][wid][px] = ss;
+  __syncthreads();
+  float vsum = 0.f;
+#pragma unroll
+  for (int w = 0; w < WAVES; ++w) vsum += red[1][w][px];
+  const float rstd = 1.f / sqrtf(vsum / (float)C + LN_EPS);
+  if (wid == 0 && slot == 0 && ok) {
+    mean_out[(long)b * HW + p] = mu;
+    rstd_out[(long)b * HW + p] = rstd;
+  }
+  if (!ok) return;
+  float* yb = y + b * y_bs + p;
+  const float shift = bias ? mu : 0.f;
+#pragma unroll
+  for (int i = 0; i < NREG; ++i) {
+    const int c = c0 + i * CSTEP;
+    if (c < C) yb[(long)c * HW] = (v[i] - shift) * rstd * weight[c] + (bias ? bias[c] : 0.f);
+  }
+}
+
+// dx (+ residual gradient) and one partial row [2][C] of dweight / dbias per workgroup; same formulas as ln_bwd_fused_kernel
+template <int NREG, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void ln_bwd_small_kernel(
+    const float* __restrict__ dy, long dy_bs, const float* __restrict__ x, long x_bs,
+    const float* __restrict__ weight, int with_bias, const float* __restrict__ mean, const float* __restrict__ rstd,
+    float* __restrict__ dx, long dx_bs, const float* __restrict__ dres, long dres_bs,
+    float* __restrict__ ws, int C, int HW, int tiles) {
+  __shared__ float red[2][WAVES][LS_PIX];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int px = lane & (LS_PIX - 1), slot = lane / LS_PIX;
+  const int b = blockIdx.x / tiles, p = (blockIdx.x % tiles) * LS_PIX + px;
+  const bool ok = p < HW;
+  const int pc = ok ? p : HW - 1;
+  const int c0 = wid * LS_SLOTS + slot;
+  constexpr int CSTEP = WAVES * LS_SLOTS;
+  const float* __restrict__ dyb = dy + b * dy_bs + pc;
+  const float* __restrict__ xb = x + b * x_bs + pc;
+  const float* __restrict__ rb = dres ? dres + b * dres_bs + pc : nullptr;
+  float* __restrict__ ob = dx + b * dx_bs + pc;
+  float* __restrict__ row = ws + (long)blockIdx.x * 2 * C;
+  const float mu = mean[(long)b * HW + pc], rs = rstd[(long)b * HW + pc];
+  float g[NREG], xh[NREG], rr[NREG];
+#pragma unroll
+  for (int i = 0; i < NREG; ++i) {           // every load of the tile in flight at once (clamped channel: no branches)
+    const int c = c0 + i * CSTEP, cc = c < C ? c : C - 1;
+    g[i] = dyb[(long)cc * HW];
+    xh[i] = xb[(long)cc * HW];
+    rr[i] = rb ? rb[(long)cc * HW] : 0.f;
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NREG; ++i) {
+    const int c = c0 + i * CSTEP;
+    const bool live = c < C;
+    const float d = live ? g[i] : 0.f;
+    const float xv = xh[i];
+    const float xn = with_bias ? (xv - mu) * rs : xv * rs;
+    const float sw = ls_sum_pixels(ok ? d * xn : 0.f), sb = ls_sum_pixels(ok ? d : 0.f);
+    if (px == 0 && live) { row[c] = sw; row[C + c] = sb; }
+    g[i] = d * weight[live ? c : 0];
+    s1 += g[i];
+    s2 += g[i] * (with_bias ? xn : xv);
+    xh[i] = with_bias ? xn : xv - mu;
+  }
+  s1 = ls_sum_slots(s1);
+  s2 = ls_sum_slots(s2);
+  if (slot == 0) { red[0][wid][px] = s1; red[1][wid][px] = s2; }
+  __syncthreads();
+  float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int w = 0; w < WAVES; ++w) { m1 += red[0][w][px]; m2 += red[1][w][px]; }
+  m1 /= (float)C; m2 /= (float)C;
+#pragma unroll
+  for (int i = 0; i < NREG; ++i) {
+    const int c = c0 + i * CSTEP;
+    if (c < C && ok) {
+      float r;
+      if (with_bias) r = rs * (g[i] - m1 - xh[i] * m2);
+      else r = rs * g[i] - rs * rs * rs * xh[i] * m2;
+      ob[(long)c * HW] = r + rr[i];
+    }
+  }
+}
+
+// small-plane variants apply when the 64-pixel tiling would leave the chip underfilled and <= 12 channels per lane suffice
+static bool ln_small(int B, int C, int HW) { return (long)B * pir_cdiv(HW, LN_PIX) < 2L * PIR_NUM_CU && C > 64 && C <= 768 && g_ln_small; }
+static int ln_small_waves(int C) { return C <= 192 ? 4 : (C <= 384 ? 8 : 16); }
+
 int ln_threads_for(int HW) { return HW >= 4096 ? 256 : (HW >= 1024 ? 128 : 64); }
 
 }  // namespace
+
+int pir_ln_tune(int knob, int value) { if (knob == 13) { g_ln_small = value; return PIR_OK; } return PIR_EINVAL; }
 
 extern "C" int pir_reduce_partials(const float* parts, long stride, int S, float alpha, int accumulate,
                                    float* out, long count, pir_stream_t stream);
@@ -283,9 +429,19 @@ extern "C" int pir_layernorm_fwd(const float* x, long x_bs, const float* weight,
                                  float* y, long y_bs, float* mean, float* rstd,
                                  int B, int C, int HW, pir_stream_t stream) {
   PIR_CHECK_ARG(x && weight && y && mean && rstd && B > 0 && C > 0 && HW > 0);
+  hipStream_t s = (hipStream_t)stream;
+  if (ln_small(B, C, HW)) {
+    const int tl = (int)pir_cdiv(HW, LS_PIX);
+    const dim3 gr((unsigned)((long)B * tl));
+    switch (ln_small_waves(C)) {
+      case 4: hipLaunchKernelGGL((ln_fwd_small_kernel<12, 4>), gr, dim3(256), 0, s, x, x_bs, weight, bias, y, y_bs, mean, rstd, C, HW, tl); break;
+      case 8: hipLaunchKernelGGL((ln_fwd_small_kernel<12, 8>), gr, dim3(512), 0, s, x, x_bs, weight, bias, y, y_bs, mean, rstd, C, HW, tl); break;
+      default: hipLaunchKernelGGL((ln_fwd_small_kernel<12, 16>), gr, dim3(1024), 0, s, x, x_bs, weight, bias, y, y_bs, mean, rstd, C, HW, tl); break;
+    }
+    return pir_launch_status();
+  }
   const int tiles = (int)pir_cdiv(HW, LN_PIX);
   dim3 grid((unsigned)((long)B * tiles));
-  hipStream_t s = (hipStream_t)stream;
 #define PIR_LN(NR, WV) hipLaunchKernelGGL((ln_fwd_kernel<NR, WV>), grid, dim3(LN_PIX * WV), 0, s, x, x_bs, weight, bias, y, y_bs, mean, rstd, C, HW, tiles)
   const bool few = (long)B * tiles < 4L * PIR_NUM_CU;   // low-resolution levels: 16 waves per pixel tile
   if (few && C > 64 && C <= 1024) {
@@ -321,7 +477,8 @@ static bool ln_use16(int B, int C, int HW) { return (long)B * pir_cdiv(HW, LN_PI
 extern "C" size_t pir_layernorm_bwd_ws_floats(int B, int C, int HW) {
   if (B <= 0 || C <= 0 || HW <= 0) return 0;
   const size_t a = (size_t)ln_param_splits(B, C, HW) * 2 * C, b = (size_t)ln_fused_blocks(B, HW, ln_use16(B, C, HW) && C > 192) * 2 * C;
-  return a > b ? a : b;
+  const size_t c = (size_t)B * pir_cdiv(HW, LS_PIX) * 2 * C;   // small-plane kernel: one partial row per 16-pixel tile
+  return (a > b ? a : b) > c ? (a > b ? a : b) : c;
 }
 
 extern "C" int pir_layernorm_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* weight,
@@ -335,7 +492,18 @@ extern "C" int pir_layernorm_bwd(const float* dy, long dy_bs, const float* x, lo
   const int tiles = (int)pir_cdiv(HW, LN_PIX);
   int S;
   const bool w16 = ln_use16(B, C, HW);
-  if (C <= 128 || w16) {
+  if (ln_small(B, C, HW)) {
+    const int tl = (int)pir_cdiv(HW, LS_PIX);
+    S = B * tl;
+    if ((size_t)S * 2 * C > ws_floats) return PIR_ENOMEM;
+    const dim3 gr((unsigned)S);
+#define PIR_LNS(WV) hipLaunchKernelGGL((ln_bwd_small_kernel<12, WV>), gr, dim3(64 * WV), 0, s, dy, dy_bs, x, x_bs, weight, with_bias, \
+      mean, rstd, dx, dx_bs, dres, dres_bs, ws, C, HW, tl)
+    switch (ln_small_waves(C)) { case 4: PIR_LNS(4); break; case 8: PIR_LNS(8); break; default: PIR_LNS(16); break; }
+#undef PIR_LNS
+    int st = pir_launch_status();
+    if (st) return st;
+  } else if (C <= 128 || w16) {
     S = ln_fused_blocks(B, HW, w16 && C > 192);   // the NREG >= 24 variants take one tile per workgroup
     if ((size_t)S * 2 * C > ws_floats) return PIR_ENOMEM;
 #define PIR_LNB(NR, WV) hipLaunchKernelGGL((ln_bwd_fused_kernel<NR, WV>), dim3((unsigned)S), dim3(LN_PIX * WV), 0, s, \

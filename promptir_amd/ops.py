@@ -837,7 +837,8 @@ class MdtaCoreFn(torch.autograd.Function):
 
 USE_SIDE_STREAM = _os.environ.get("PIR_SIDE_STREAM", "1") != "0"   # default for callers outside a trainer
 MDTA_FOLD = _os.environ.get("PIR_MDTA_FOLD", "1") != "0"             # fold attn @ v into project_out (TransformerBlockFn)
-MDTA_FOLD_MIN_HW = int(_os.environ.get("PIR_MDTA_FOLD_MIN_HW", "0")) # ... for planes of at least this many pixels
+MDTA_FOLD_MIN_HW = int(_os.environ.get("PIR_MDTA_FOLD_MIN_HW", "4096"))   # ... at the 64^2 / 128^2 levels (below, the
+# C x C x c products it adds cost as much as the launch-bound GEMMs it removes: bench A/B, round 2)
 _SIDE_STREAMS = {}
 _SIDE_OVERRIDE = []   # innermost `side_streams(...)` scope wins over the module default
 

@@ -107,8 +107,18 @@ def bench_dw(B):
 
 
 def bench_ln(B):
-    print("== LayerNorm ==")
-    for name, C, S, heads in LEVELS:
+    from promptir_amd import _lib
+    print("== LayerNorm (knob 13 = 0: 64-pixel tiles only; 1: 16-pixel tiles on small planes) ==")
+    for name, C, S, heads in LEVELS + [("noise2 C320 32^2", 320, 32, 4)]:
+      for knob in (0, 1):
+        _lib.lib.pir_tune_set(13, knob)
+        name_k = f"{name} k{knob}"
+        bench_ln_one(name_k, B, C, S)
+    _lib.lib.pir_tune_set(13, 1)
+
+
+def bench_ln_one(name, B, C, S):
+    if True:
         x, w, b = r(B, C, S, S), torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
         t = timeit(lambda: ops.layernorm_forward(x, w, b))
         print(f"{name:18s} ln fwd: {t*1e6:8.1f} us {8.0*x.numel()/t/1e9:7.0f} GB/s")
