@@ -189,14 +189,15 @@ class DataParallelTrainer:
         # The batch is cut into parts that run on their own HIP streams: the kernels of one part (say a
         # bandwidth-bound stencil) run beside those of another (an MFMA-bound GEMM) and fill each other's idle
         # units.  Each part writes its weight gradients into its own flat buffer (the sinks are captured at
-        # forward time); the parts are summed once.  Measured at batch 32 inside the hipGraph: 1 stream 131.9 ms,
-        # 2: 125.0, 3: 122.9, 4: 122.3 (eager, two streams: 142.9 ms - the doubled launch count makes the CPU
-        # the bottleneck, which is why this lives inside the graph).
+        # forward time); the parts are summed once.  Measured at batch 32 inside the hipGraph, round 2 kernels: 1 stream
+        # 106.4 ms, 2: 101.8, 3: 102.1, 4: 103.7, 6: 124.2 (round 1, slower streaming kernels: 131.9 / 125.0 / 122.9 /
+        # 122.3 - the better the bandwidth-bound kernels fill the chip on their own, the less a second part helps).
+        # Eagerly the doubled launch count makes the CPU the bottleneck, which is why this lives inside the graph.
         if graph is None:
             graph = os.environ.get("PIR_GRAPH", "1") != "0"
         self.graph, self._graph, self._graph_shape = bool(graph) and self.opt.param.is_cuda, None, None
         if micro_streams is None:   # part streams only pay inside the graph (eagerly the extra launches bind the CPU)
-            micro_streams = int(os.environ.get("PIR_MICRO_STREAMS", "4" if self.graph else "1"))
+            micro_streams = int(os.environ.get("PIR_MICRO_STREAMS", "2" if self.graph else "1"))
         self.micro_streams = max(1, micro_streams) if self.opt.param.is_cuda else 1
         self._split_sig = None
         if self.micro_streams > 1:
