@@ -332,11 +332,27 @@ class PromptIR(nn.Module):
                                f"H, W must be multiples of 8, got {list(inp_img.shape[2:])}")
         ops._require_gpu(inp_img)
 
+        return self.decode(inp_img, *self.encode(inp_img))
+
+    # The forward in three pieces (net/model.py:324-334 | :336-337 | :339-377).  A data-parallel trainer cuts the
+    # autograd graph between them so that the gradient all-reduce of a finished piece overlaps the backward of the
+    # next one (promptir_amd/train.py); `forward` is their composition.
+    def encode_levels(self, inp_img):
+        """patch_embed, encoder levels 1-3 and the three downsamplings -> (enc1, enc2, enc3, latent input)."""
         inp_enc_level1 = self.patch_embed(inp_img)
         out_enc_level1 = self.encoder_level1(inp_enc_level1)
         out_enc_level2 = self.encoder_level2(self.down1_2(out_enc_level1))
         out_enc_level3 = self.encoder_level3(self.down2_3(out_enc_level2))
-        latent = self.latent(self.down3_4(out_enc_level3))
+        return out_enc_level1, out_enc_level2, out_enc_level3, self.down3_4(out_enc_level3)
+
+    def run_latent(self, inp_latent):
+        return self.latent(inp_latent)
+
+    def encode(self, inp_img):
+        out_enc_level1, out_enc_level2, out_enc_level3, inp_latent = self.encode_levels(inp_img)
+        return self.run_latent(inp_latent), out_enc_level3, out_enc_level2, out_enc_level1
+
+    def decode(self, inp_img, latent, out_enc_level3, out_enc_level2, out_enc_level1):
         if self.decoder:
             latent = _cat(latent, self.prompt3(latent))
             latent = self.reduce_noise_level3(self.noise_level3(latent))
@@ -356,3 +372,13 @@ class PromptIR(nn.Module):
         inp_dec_level1 = _cat(self.up2_1(out_dec_level2), out_enc_level1)
         out_dec_level1 = self.refinement(self.decoder_level1(inp_dec_level1))
         return self.output(out_dec_level1, residual=inp_img)   # `+ inp_img` fused into the conv epilogue
+
+    # which piece owns a parameter (for the trainer's gradient segments): 0 encoder levels, 1 latent, 2 the rest
+    @staticmethod
+    def stage_of(param_name: str) -> int:
+        head = param_name.split(".", 1)[0]
+        if head in ("patch_embed", "encoder_level1", "encoder_level2", "encoder_level3", "down1_2", "down2_3", "down3_4"):
+            return 0
+        if head == "latent":
+            return 1
+        return 2

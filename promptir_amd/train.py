@@ -64,6 +64,15 @@ class FlatAdamW:
         self.named = live_parameters(net, unused_prefixes)
         if not self.named:
             raise ValueError("no parameters")
+        # Gradient segments: when the module can say which piece of its forward owns a parameter (PromptIR.stage_of),
+        # the flat buffers are laid out piece by piece, so the gradients a backward segment completes form ONE
+        # contiguous range that can be all-reduced while the next segment runs.  (Checkpoints address parameters by
+        # name, so the order inside the flat buffers is free.)
+        stage_of = getattr(net, "stage_of", None)
+        self.stages = None
+        if callable(stage_of):
+            order = sorted(range(len(self.named)), key=lambda i: (stage_of(self.named[i][0]), i))
+            self.named = [self.named[i] for i in order]
         dev = self.named[0][1].device
         self.offsets: Dict[str, int] = {}
         off = 0
@@ -72,6 +81,13 @@ class FlatAdamW:
             off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         self.numel = off
         self.live_numel = sum(p.numel() for _, p in self.named)
+        if callable(stage_of):   # [begin, end) of every stage's slice of the flat buffers
+            self.stages, begin, cur = [], 0, stage_of(self.named[0][0])
+            for n, _ in self.named:
+                if stage_of(n) != cur:
+                    self.stages.append((begin, self.offsets[n]))
+                    begin, cur = self.offsets[n], stage_of(n)
+            self.stages.append((begin, off))
         self.param = torch.zeros(off, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(off, dtype=torch.float32, device=dev)
@@ -200,6 +216,11 @@ class DataParallelTrainer:
             micro_streams = int(os.environ.get("PIR_MICRO_STREAMS", "2" if self.graph else "1"))
         self.micro_streams = max(1, micro_streams) if self.opt.param.is_cuda else 1
         self._split_sig = None
+        self._seg_state = None
+        # backward in three segments with the gradient all-reduce of each finished range overlapping the next segment:
+        # on by default whenever gradients are exchanged between ranks (PIR_STAGED=1 forces it for single-rank tests)
+        self.staged = (os.environ.get("PIR_STAGED", "1" if self.world > 1 else "0") != "0" and self.opt.param.is_cuda
+                       and self._staged_ok())
         if self.micro_streams > 1:
             dev = self.opt.param.device
             n = self.micro_streams
@@ -268,7 +289,149 @@ class DataParallelTrainer:
             total = loss.detach() * w if total is None else total + loss.detach() * w
         return total
 
+    # ---- gradient all-reduce overlapped with backward (reference: DDP's bucketed all-reduce, train.py:339) ----------
+    # The forward is cut into three pieces (PromptIR.encode_levels | run_latent | decode); the backward then runs as
+    # three segments - decoder side, latent, encoder levels - each leaving ONE contiguous range of the flat gradient
+    # complete (FlatAdamW lays the parameters out piece by piece).  The all-reduce of a finished range is issued
+    # asynchronously (RCCL works on its own stream) and overlaps the next segment; only the last and smallest range
+    # (encoder levels: 9 % of the parameters, 13 MB) is exposed.  Every segment is its own hipGraph (the first one also
+    # holds the forward); eager mode runs the same segments.
+    def _staged_ok(self) -> bool:
+        return self.opt.stages is not None and len(self.opt.stages) == 3 and hasattr(self.net, "encode_levels")
+
+    def _parts(self, b: int):
+        n = min(self.micro_streams, max(1, b // 4))      # parts of at least four samples
+        return n, [b * i // n for i in range(n + 1)]
+
+    def _fork(self, n: int, device):
+        main = torch.cuda.current_stream(device)
+        if n == 1:
+            return main, [main]
+        ev = torch.cuda.Event()
+        ev.record(main)
+        for st in self._streams[:n]:
+            st.wait_event(ev)
+        return main, self._streams[:n]
+
+    @staticmethod
+    def _join(main, streams) -> None:
+        for st in streams:
+            if st is not main:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                main.wait_event(ev)
+
+    def _sum_range(self, stage: int, n: int) -> None:
+        """Part gradients of one stage's range summed into the primary flat buffer (mean over the batch: the parts'
+        losses carry their share of the batch as upstream gradient)."""
+        from . import ops
+
+        lo, hi = self.opt.stages[stage]
+        for i in range(1, n):
+            ops.add_(self.opt.grad[lo:hi], self._grads[i][lo:hi])
+
+    def _seg_forward_and_decoder(self, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        """Segment 0: forward of every part, loss, backward of the decoder piece.  Leaves stage 2's gradient range
+        complete and returns the batch loss."""
+        b = x.shape[0]
+        n, bounds = self._parts(b)
+        main, streams = self._fork(n, x.device)
+        self._seg_state = []
+        for i, st in enumerate(streams):
+            lo, hi = bounds[i], bounds[i + 1]
+            if n > 1:
+                self._use_sinks(i)                   # captured by the autograd nodes of this forward
+            with torch.cuda.stream(st):
+                enc = self.net.encode_levels(x[lo:hi])
+                enc_cut = [e.detach().requires_grad_() for e in enc]
+                lat = self.net.run_latent(enc_cut[3])
+                lat_cut = lat.detach().requires_grad_()
+                y = self.net.decode(x[lo:hi], lat_cut, enc_cut[2], enc_cut[1], enc_cut[0])
+                w = torch.full((), (hi - lo) / b, dtype=torch.float32, device=x.device)
+                self._seg_state.append({"enc": enc, "enc_cut": enc_cut, "lat": lat, "lat_cut": lat_cut,
+                                        "loss": self.loss_fn(y, t[lo:hi]), "w": w})
+        for p, st in zip(self._seg_state, streams):
+            with torch.cuda.stream(st):
+                p["loss"].backward(gradient=p["w"])
+        self._join(main, streams)
+        if n > 1:
+            self._use_sinks(0)
+        self._sum_range(2, n)
+        total = None
+        for p in self._seg_state:                    # mean over the batch = sum of the weighted parts
+            total = p["loss"].detach() * p["w"] if total is None else total + p["loss"].detach() * p["w"]
+        return total
+
+    def _seg_latent(self, device) -> None:
+        """Segment 1: backward of the latent blocks (stage 1's range)."""
+        n = len(self._seg_state)
+        main, streams = self._fork(n, device)
+        for p, st in zip(self._seg_state, streams):
+            with torch.cuda.stream(st):
+                p["lat"].backward(p["lat_cut"].grad)
+        self._join(main, streams)
+        self._sum_range(1, n)
+
+    def _seg_encoder(self, device) -> None:
+        """Segment 2: backward of the encoder levels (stage 0's range)."""
+        n = len(self._seg_state)
+        main, streams = self._fork(n, device)
+        for p, st in zip(self._seg_state, streams):
+            with torch.cuda.stream(st):
+                torch.autograd.backward(list(p["enc"]), [c.grad for c in p["enc_cut"]])
+        self._join(main, streams)
+        self._sum_range(0, n)
+
+    def _staged_eager(self, x: torch.Tensor, t: torch.Tensor, reduce_async=None) -> torch.Tensor:
+        from . import ops
+
+        with ops.side_streams(False):
+            loss = self._seg_forward_and_decoder(x, t)
+            if reduce_async:
+                reduce_async(2)
+            self._seg_latent(x.device)
+            if reduce_async:
+                reduce_async(1)
+            self._seg_encoder(x.device)
+        self._seg_state = None
+        return loss.detach()
+
+    def _capture_staged(self, x: torch.Tensor, t: torch.Tensor) -> None:
+        from . import ops
+
+        self._sx, self._st = x.clone(), t.clone()
+        side = torch.cuda.Stream(x.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                # warm-up outside any error handling (see _capture)
+            for _ in range(2):
+                self._staged_eager(self._sx, self._st)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
+        try:
+            with ops.side_streams(False):
+                with torch.cuda.graph(graphs[0], capture_error_mode="thread_local"):
+                    sloss = self._seg_forward_and_decoder(self._sx, self._st)
+                pool = graphs[0].pool()              # later segments read tensors the first one produced
+                with torch.cuda.graph(graphs[1], pool=pool, capture_error_mode="thread_local"):
+                    self._seg_latent(x.device)
+                with torch.cuda.graph(graphs[2], pool=pool, capture_error_mode="thread_local"):
+                    self._seg_encoder(x.device)
+        except RuntimeError as exc:
+            msg = str(exc).lower()
+            if not any(k in msg for k in ("captur", "graph")):
+                raise
+            raise _CaptureRefused(str(exc)) from exc
+        self._seg_state = None
+        self._graph, self._sloss = graphs, sloss
+        self._graph_shape = tuple(x.shape)
+
     def _capture(self, degrad_patch: torch.Tensor, clean_patch: torch.Tensor) -> None:
+        if self.staged:
+            return self._capture_staged(degrad_patch, clean_patch)
+        self._capture_whole(degrad_patch, clean_patch)
+
+    def _capture_whole(self, degrad_patch: torch.Tensor, clean_patch: torch.Tensor) -> None:
         """hipGraph of forward + loss + backward on static input buffers.  The optimiser, the
         all-reduce and the weight re-split stay outside (their arguments change from step to step)."""
         self._sx, self._st = degrad_patch.clone(), clean_patch.clone()
@@ -308,6 +471,7 @@ class DataParallelTrainer:
             warnings.warn(f"hipGraph capture refused ({exc}); falling back to the eager single-stream step")
             torch.cuda.synchronize()
             self.graph, self._graph, self.micro_streams = False, None, 1
+            self._seg_state = None
             self._use_sinks_default()
 
     def prepare(self, degrad_patch: torch.Tensor, clean_patch: torch.Tensor) -> None:
@@ -315,10 +479,12 @@ class DataParallelTrainer:
         if self.graph and degrad_patch.is_cuda:
             self._ensure_graph(degrad_patch, clean_patch)
 
-    def forward_backward(self, degrad_patch: torch.Tensor, clean_patch: torch.Tensor) -> torch.Tensor:
+    def forward_backward(self, degrad_patch: torch.Tensor, clean_patch: torch.Tensor, between=None) -> torch.Tensor:
         """forward + L1 + backward of one batch (reference train.py:37-46 + Lightning's loss.backward()): leaves the
         local batch-mean gradient in the flat buffer `opt.grad` and returns the loss (device scalar).  hipGraph
-        replay when enabled, eager launches otherwise."""
+        replay when enabled, eager launches otherwise.  Staged mode: `between(stage)` is called as soon as the
+        backward segment that completes gradient range `stage` has been enqueued (stages 2 and 1; the caller handles
+        the final range 0 itself)."""
         if not degrad_patch.is_cuda:
             return self._fwd_bwd(degrad_patch, clean_patch)
         from . import ops
@@ -335,15 +501,48 @@ class DataParallelTrainer:
                 self._split_sig = ops.split_weights_signature()
             self._sx.copy_(degrad_patch)
             self._st.copy_(clean_patch)
+            if self.staged:        # three segment graphs; `between(stage)` runs after the segment that completes `stage`
+                self._graph[0].replay()
+                loss = self._sloss.clone()
+                if between:
+                    between(2)
+                self._graph[1].replay()
+                if between:
+                    between(1)
+                self._graph[2].replay()
+                return loss
             self._graph.replay()
             return self._sloss.clone()
+        if self.staged and ops.lib.records is None:
+            return self._staged_eager(degrad_patch, clean_patch, between)
         # eager; the instrumented (per-kernel timed) step stays on one stream
         return self._fwd_bwd(degrad_patch, clean_patch, two_streams=ops.lib.records is None)
 
     def train_step(self, degrad_patch: torch.Tensor, clean_patch: torch.Tensor, lr: Optional[float] = None):
         """reference train.py:37-46 (+ optimizer.step of Lightning's loop)."""
-        loss = self.forward_backward(degrad_patch, clean_patch)
-        scale = allreduce_mean_(self.opt.grad, self.world)
+        if self.staged and degrad_patch.is_cuda and dist.is_initialized():
+            from . import ops
+
+            staged_now = ops.lib.records is None
+        else:
+            staged_now = False
+        if staged_now:
+            # asynchronous all-reduce of each gradient range as soon as its backward segment has been enqueued: RCCL
+            # orders it behind the work already on this stream and runs it on its own stream beside the next segment
+            pending = []
+
+            def reduce_range(stage: int) -> None:
+                lo, hi = self.opt.stages[stage]
+                pending.append(dist.all_reduce(self.opt.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+
+            loss = self.forward_backward(degrad_patch, clean_patch, between=reduce_range)
+            reduce_range(0)
+            for work in pending:
+                work.wait()
+            scale = 1.0 / self.world
+        else:
+            loss = self.forward_backward(degrad_patch, clean_patch)
+            scale = allreduce_mean_(self.opt.grad, self.world)
         self.opt.step(lr=lr, grad_scale=scale)
         if self.graph and self.opt.param.is_cuda:
             from . import ops

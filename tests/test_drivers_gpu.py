@@ -72,13 +72,14 @@ def test_bench_runs_under_an_rccl_process_group():
 
     out = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
                 "--batch", "8", "--no-cpu-baseline"],
-               {"PIR_FORCE_PG": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533", "RANK": "0", "WORLD_SIZE": "1",
-                "LOCAL_RANK": "0"})
+               {"PIR_FORCE_PG": "1", "PIR_STAGED": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533", "RANK": "0",
+                "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 1 and rec["config"]["process_group"] == "nccl"
     assert rec["config"]["execution"].startswith("hipGraph=1")
+    assert "overlapped" in rec["config"]["execution"]      # the N>1 mode: three segment graphs, async RCCL all-reduces
     assert rec["config"]["step1_loss_check"]["ok"] is True
 
 
