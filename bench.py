@@ -112,8 +112,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=None,
-                    help="patches per GPU; default 32 at N=1 (BASELINE config 3), 8 at N>1 (BASELINE config 5)")
+    ap.add_argument("--batch", type=int, default=32,
+                    help="patches per GPU of the headline line: 32 = BASELINE config 3 at N=1, the same per-GPU work at every "
+                         "N (weak scaling); BASELINE config 5 (batch 8 per GPU) is measured beside it when N > 1")
+    ap.add_argument("--config5", type=int, default=None,
+                    help="1: also time BASELINE config 5's per-GPU batch 8 and report it under `config5` (default: when N > 1)")
     ap.add_argument("--patch", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -127,10 +130,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device: the HIP path has no CPU fallback")
     device = torch.device("cuda", local)
-    if args.batch is None:
-        args.batch = 32 if world == 1 else 8
-    baseline_cfg = {(1, 32): "BASELINE config 3", (0, 8): "BASELINE config 5 (per-GPU batch 8, DDP)"}.get(
-        (1 if world == 1 else 0, args.batch), "non-BASELINE batch size")
+    if args.batch == 32:
+        baseline_cfg = "BASELINE config 3" if world == 1 else "BASELINE config 3's batch per GPU, data-parallel over %d GPUs" % world
+    elif args.batch == 8 and world > 1:
+        baseline_cfg = "BASELINE config 5"
+    else:
+        baseline_cfg = "non-BASELINE batch size"
+    want_config5 = (world > 1 and args.batch != 8) if args.config5 is None else bool(args.config5)
 
     net, sd = build_model(device)
     trainer = DataParallelTrainer(net, lr=2e-4)
@@ -163,6 +169,28 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # BASELINE config 5 (DDP, batch 8 per GPU) beside the headline line: same trainer, graph re-captured for the shape
+    config5 = None
+    if want_config5:
+        x8, t8 = build_batch(8, args.patch, rank, device)
+        trainer.prepare(x8, t8)
+        for _ in range(args.warmup):
+            trainer.train_step(x8, t8)
+        sync()
+        t5 = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.train_step(x8, t8)
+        sync()
+        e5 = time.perf_counter() - t5
+        if world > 1:
+            tm = torch.tensor([e5], dtype=torch.float64, device=device)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            e5 = float(tm.item())
+        config5 = {"workload": "BASELINE config 5: batch 8/GPU x 3x%dx%d, DDP over %d GPU(s)" % (args.patch, args.patch, world),
+                   "global_batch": 8 * world, "value": round(8 * world * args.steps / e5, 3), "unit": "patches/s",
+                   "ms_per_step": round(e5 / args.steps * 1e3, 3), "per_gpu_value": round(8 * args.steps / e5, 3)}
+        trainer.prepare(x, t)      # back to the headline shape for the instrumented step below
+
     roofline, cpu = None, None
     if rank == 0:
         # one extra instrumented step: HIP events around every C-ABI call on the launch stream
@@ -183,11 +211,13 @@ def main():
         # HBM bytes per launch from the committed PMC profile of this build (rocprofv3 cannot run inside the timed
         # process): FETCH_SIZE x 2 (gfx950 wide-read correction) + WRITE_SIZE, averaged over the family's launches
         traffic, traffic_note = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_final_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if x3 and args.batch == 32 and os.path.exists(tpath):
             tj = json.load(open(tpath))
-            traffic = round((2.0 * tj["fetch_kb_per_launch_raw"] + tj["write_kb_per_launch"]) * 1e3)
-            traffic_note = tj["source"] + "; " + tj["note"]
+            fam_t = tj["families"].get("pir_gemm_nn")
+            if fam_t:
+                traffic = round((2.0 * fam_t["fetch_kb_per_launch_raw"] + fam_t["write_kb_per_launch"]) * 1024)
+                traffic_note = "profiles/r02_traffic.json: " + tj["source"] + "; " + tj["note"]
         roofline = {"kernel": ("gemm_nn_x3_kernel" if x3 else "gemm_nn_kernel") + " (all instantiations behind pir_gemm_nn)",
                     "bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
@@ -221,7 +251,7 @@ def main():
                        "process_group": dist.get_backend() if dist.is_initialized() else None,
                        "params": 35592263, "final_loss": float(loss), "step1_loss_check": loss_check},
             "per_gpu_value": round(patches / elapsed / world, 3),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "config5": config5,
         }
         print(json.dumps(out), flush=True)
     if dist.is_initialized():

@@ -80,6 +80,7 @@ def test_bench_runs_under_an_rccl_process_group():
     assert rec["n_gpus"] == 1 and rec["config"]["process_group"] == "nccl"
     assert rec["config"]["execution"].startswith("hipGraph=1")
     assert "overlapped" in rec["config"]["execution"]      # the N>1 mode: three segment graphs, async RCCL all-reduces
+    assert rec["config5"] is None                          # --batch 8 IS config 5
     assert rec["config"]["step1_loss_check"]["ok"] is True
 
 

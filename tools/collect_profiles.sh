@@ -23,4 +23,10 @@ STEPS=1 run pmc_fetch "$EAGER" --kernel-trace --pmc FETCH_SIZE
 STEPS=1 run pmc_write "$EAGER" --kernel-trace --pmc WRITE_SIZE
 cd "$ROOT"
 python3 tools/pmc_summary.py "$OUT" > "$OUT/summary.txt" 2> "$OUT/summary.err"
-ls "$OUT"
+# keep the per-kernel statistics, drop the raw per-dispatch CSVs (tens of MB: gpurun merges at most 64 MiB back)
+for t in trace_eager trace_graph; do
+  f=$(find "$OUT/$t" -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp "$f" "$OUT/${t}_kernel_stats.csv"
+done
+rm -rf "$OUT"/trace_eager "$OUT"/trace_graph "$OUT"/pmc_mfma "$OUT"/pmc_wait "$OUT"/pmc_grbm "$OUT"/pmc_fetch "$OUT"/pmc_write
+ls -la "$OUT"
