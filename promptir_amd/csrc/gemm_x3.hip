@@ -26,6 +26,16 @@
 #define X3_FILL 0   // N > 0: place N conversion VALU ops behind each MFMA of the main loop (measured: no gain)
 #endif
 
+#ifdef X3_TRACE   // tools/x3_trace.py: per-workgroup phase clocks of wave 0 (never defined in the product build)
+__device__ unsigned long long* x3_trace_buf;
+extern "C" int pir_x3_trace_set(unsigned long long* p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(x3_trace_buf), &p, sizeof(p));
+}
+#define X3_MARK(i) do { if (x3_tr && threadIdx.x == 0) x3_tr[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define X3_MARK(i) do { } while (0)
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -73,6 +83,14 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
   const float* __restrict__ A = g.A + o1 * g.a_s1 + o2 * g.a_s2;
   const float* __restrict__ X = g.X + o1 * g.x_s1 + o2 * g.x_s2;
   float* __restrict__ Y = g.Y + o1 * g.y_s1 + o2 * g.y_s2;
+#ifdef X3_TRACE
+  unsigned long long* x3_tr = x3_trace_buf ? x3_trace_buf + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+  if (x3_tr && threadIdx.x == 0) {
+    x3_tr[5] = __builtin_amdgcn_s_memrealtime();
+    x3_tr[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+  }
+#endif
+  X3_MARK(0);
 
   constexpr int AF = 2 * BM, NA = (AF + T - 1) / T;   // 8-deep k fragments per stage
   constexpr int BF = 2 * BN, NB = (BF + T - 1) / T;
@@ -250,6 +268,7 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
   if (iters > 1) load(1, s1);
   stash(0, 0, s0);
   __syncthreads();
+  X3_MARK(1);
   int it = 0;
   // Main part: both prefetch loads are in range, so they sit in the same basic block as the MFMAs and the
   // scheduler can be told to issue one vector-memory instruction behind each MFMA.  In-kernel cycle counters
@@ -282,8 +301,15 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
     __syncthreads();
   }
   if (it < iters) compute(0);
+  X3_MARK(2);
 
   pir_nn_epilogue<TM, TN>(acc, g, Y, o1, o2, m0, n0, wm, wn, lane);
+#ifdef X3_TRACE
+  X3_MARK(3);
+  __builtin_amdgcn_s_waitcnt(0);   // stores acknowledged
+  X3_MARK(4);
+  if (x3_tr && threadIdx.x == 0) x3_tr[6] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 template <int TM, int TN, int WM, int WN>
