@@ -22,6 +22,15 @@
 #ifndef X3_VMEM_FILL
 #define X3_VMEM_FILL 1   // issue the prefetch loads one per MFMA inside the main loop
 #endif
+#ifndef X3_ABLATE
+#define X3_ABLATE 0   // tools/x3_ablate.sh (never set in the product build; results are garbage): 1 every stage re-reads
+#endif                // stage 0 (cache hits), 2 no MFMAs, 4 no split arithmetic, 8 one store in sixteen, 16 no barriers in
+                      // the k loop, 32 no LDS writes, 64 one LDS read per fragment set, 128 no global loads after the prologue
+#if X3_ABLATE & 16
+#define X3_SYNC() do { } while (0)
+#else
+#define X3_SYNC() __syncthreads()
+#endif
 #ifndef X3_FILL
 #define X3_FILL 0   // N > 0: place N conversion VALU ops behind each MFMA of the main loop (measured: no gain)
 #endif
@@ -32,8 +41,12 @@ extern "C" int pir_x3_trace_set(unsigned long long* p) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(x3_trace_buf), &p, sizeof(p));
 }
 #define X3_MARK(i) do { if (x3_tr && threadIdx.x == 0) x3_tr[i] = __builtin_amdgcn_s_memtime(); } while (0)
+// phase sums inside the k loop (wave 0): PH(i) closes phase i = the time since the previous stamp
+#define X3_PH(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                      x3_ph[i] += t_ - x3_last; x3_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define X3_MARK(i) do { } while (0)
+#define X3_PH(i) do { } while (0)
 #endif
 
 namespace {
@@ -46,6 +59,12 @@ struct Frag3 { bf16x8 hi, mid, lo; };
 
 __device__ __forceinline__ Frag3 split8(const float (&v)[8], bool ok) {
   Frag3 f;
+#if X3_ABLATE & 4
+  u32x4 w = {__builtin_bit_cast(unsigned, v[0]) ^ __builtin_bit_cast(unsigned, v[4]), __builtin_bit_cast(unsigned, v[1]) ^ __builtin_bit_cast(unsigned, v[5]),
+             __builtin_bit_cast(unsigned, v[2]) ^ __builtin_bit_cast(unsigned, v[6]), __builtin_bit_cast(unsigned, v[3]) ^ __builtin_bit_cast(unsigned, v[7])};
+  f.hi = f.mid = f.lo = __builtin_bit_cast(bf16x8, w);
+  return f;
+#endif
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const float x = ok ? v[j] : 0.f;
@@ -84,12 +103,14 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
   const float* __restrict__ X = g.X + o1 * g.x_s1 + o2 * g.x_s2;
   float* __restrict__ Y = g.Y + o1 * g.y_s1 + o2 * g.y_s2;
 #ifdef X3_TRACE
-  unsigned long long* x3_tr = x3_trace_buf ? x3_trace_buf + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+  unsigned long long* x3_tr = x3_trace_buf ? x3_trace_buf + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 16 : nullptr;
   if (x3_tr && threadIdx.x == 0) {
     x3_tr[5] = __builtin_amdgcn_s_memrealtime();
     x3_tr[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
   }
 #endif
+  unsigned long long x3_ph[4] = {0, 0, 0, 0}, x3_last = 0;
+  (void)x3_ph; (void)x3_last;
   X3_MARK(0);
 
   constexpr int AF = 2 * BM, NA = (AF + T - 1) / T;   // 8-deep k fragments per stage
@@ -134,7 +155,8 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
   const int a3_part_bytes = (CONV ? 9 : 1) * g.M * g.a3_kp * 2, a3_step_bytes = g.M * 32, ldx4 = (int)g.ldx * 4;
 
   auto load = [&](int it_raw, Stage& st) {
-    const int it = it_raw < iters ? it_raw : iters - 1;
+    if ((X3_ABLATE & 128) && it_raw >= 2) return;
+    const int it = (X3_ABLATE & 1) ? 0 : it_raw < iters ? it_raw : iters - 1;
     int tap = 0, ks = it;
     if (CONV) { tap = pir_fastdiv(it, cv.magic_ks); ks = it - tap * cv.ksteps; }
     const int k0 = ks * XK, klast = g.K - 1 - k0;
@@ -181,7 +203,7 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
       if (AF % T == 0 || f < AF) {
         const int u = kg * AKS + mm;
         if (A_PRE) {  // rows beyond M only feed masked outputs: no zeroing needed
-          base[u] = st.a3[i][0]; base[PART + u] = st.a3[i][1]; base[2 * PART + u] = st.a3[i][2];
+          if (!(X3_ABLATE & 32) || st.a3[i][0][0] == (__bf16)12345.f) { base[u] = st.a3[i][0]; base[PART + u] = st.a3[i][1]; base[2 * PART + u] = st.a3[i][2]; }
         } else {
           // a fragment is all-or-nothing in m; k beyond K is zeroed element-wise
           float v[8];
@@ -201,7 +223,7 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
       const int nn = f % BN, kg = f / BN;
       const Frag3 fr = split8(st.b[i], true);   // k tail already zero (range-checked loads)
       const int u = AU + kg * BN + nn;
-      base[u] = fr.hi; base[PART + u] = fr.mid; base[2 * PART + u] = fr.lo;
+      if (!(X3_ABLATE & 32) || fr.hi[0] == (__bf16)12345.f) { base[u] = fr.hi; base[PART + u] = fr.mid; base[2 * PART + u] = fr.lo; }
     }
   };
   auto stash = [&](int buf, int it, const Stage& st) {
@@ -237,15 +259,21 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
     const bf16x8* bp = base + AU + h * BN + wn * TN * 32 + r;
     bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) { ah[i] = ap[i * 32]; am[i] = ap[PART + i * 32]; al[i] = ap[2 * PART + i * 32]; }
+    for (int i = 0; i < TM; ++i) { ah[i] = ap[(X3_ABLATE & 64) ? 0 : i * 32]; am[i] = (X3_ABLATE & 64) ? ah[i] : ap[PART + i * 32]; al[i] = (X3_ABLATE & 64) ? ah[i] : ap[2 * PART + i * 32]; }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) { bh[j] = bp[j * 32]; bm[j] = bp[PART + j * 32]; bl[j] = bp[2 * PART + j * 32]; }
+    for (int j = 0; j < TN; ++j) { bh[j] = (X3_ABLATE & 64) ? ah[0] : bp[j * 32]; bm[j] = (X3_ABLATE & 64) ? ah[0] : bp[PART + j * 32]; bl[j] = (X3_ABLATE & 64) ? ah[0] : bp[2 * PART + j * 32]; }
     // term-major order: consecutive MFMAs go to DIFFERENT accumulators (the per-accumulator order of the six
     // terms, hence the result, is unchanged).  Left accumulator-major, the compiler emits six back-to-back
     // dependent MFMAs per accumulator.
+#if X3_ABLATE & 2
+#define PIR_X3_TERM(A_, B_)                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
+        acc[i][j][0] += __builtin_bit_cast(float, (int)A_[i][0] ^ (int)B_[j][1]);
+#else
 #define PIR_X3_TERM(A_, B_)                                                                   \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[i], B_[j], acc[i][j], 0, 0, 0);
+#endif
     if (X3_MFMA_PRIO > 0) __builtin_amdgcn_s_setprio(X3_MFMA_PRIO);
     if (X3_MFMA_PRIO < 0) __builtin_amdgcn_s_setprio(0);
     PIR_X3_TERM(al, bh)
@@ -269,36 +297,59 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
   stash(0, 0, s0);
   __syncthreads();
   X3_MARK(1);
+#ifdef X3_TRACE
+  x3_last = __builtin_amdgcn_s_memtime();
+#endif
   int it = 0;
   // Main part: both prefetch loads are in range, so they sit in the same basic block as the MFMAs and the
   // scheduler can be told to issue one vector-memory instruction behind each MFMA.  In-kernel cycle counters
   // showed the load issue of a stage (19 instructions, ~40 cycles each in the wave's in-order stream) costing
   // ~820 cycles per k-step in front of 1152 cycles of MFMAs.
   for (; it + 3 < iters; it += 2) {
+#ifdef X3_TRACE   // stamped build: three phases per k-step, schedule pinned at the stamps
+    load(it + 2, s0);
+    compute(0);
+    X3_PH(0);
+    stash_b(1, s1);
+    stash_a(1, it + 1, s1);
+    X3_PH(1);
+    __syncthreads();
+    X3_PH(2);
+    load(it + 3, s1);
+    compute(1);
+    X3_PH(0);
+    stash_b(0, s0);
+    stash_a(0, it + 2, s0);
+    X3_PH(1);
+    __syncthreads();
+    X3_PH(2);
+    x3_ph[3] += 2;
+#else
     load(it + 2, s0);
     compute(0);
     stash_b(1, s1);
     if (X3_VMEM_FILL) interleave();
     stash_a(1, it + 1, s1);
-    __syncthreads();
+    X3_SYNC();
     load(it + 3, s1);
     compute(1);
     stash_b(0, s0);
     if (X3_VMEM_FILL) interleave();
     stash_a(0, it + 2, s0);
-    __syncthreads();
+    X3_SYNC();
+#endif
   }
   for (; it + 1 < iters; it += 2) {   // tail: at most three stages left, loads guarded
     if (it + 2 < iters) load(it + 2, s0);
     compute(0);
     stash_b(1, s1);
     stash_a(1, it + 1, s1);
-    __syncthreads();
+    X3_SYNC();
     if (it + 3 < iters) load(it + 3, s1);
     compute(1);
     stash_b(0, s0);   // harmless past the end (slot 0 is not read again)
     if (it + 2 < iters) stash_a(0, it + 2, s0);
-    __syncthreads();
+    X3_SYNC();
   }
   if (it < iters) compute(0);
   X3_MARK(2);
@@ -308,7 +359,10 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
   X3_MARK(3);
   __builtin_amdgcn_s_waitcnt(0);   // stores acknowledged
   X3_MARK(4);
-  if (x3_tr && threadIdx.x == 0) x3_tr[6] = __builtin_amdgcn_s_memrealtime();
+  if (x3_tr && threadIdx.x == 0) {
+    x3_tr[6] = __builtin_amdgcn_s_memrealtime();
+    for (int q = 0; q < 4; ++q) x3_tr[8 + q] = x3_ph[q];
+  }
 #endif
 }
 

@@ -19,7 +19,7 @@ lib = _lib.lib
 lib.pir_x3_trace_set.restype = ctypes.c_int
 lib.pir_x3_trace_set.argtypes = [ctypes.c_void_p]
 NWG = 1 << 18
-trace = torch.zeros(NWG * 8, dtype=torch.int64, device="cuda:0")
+trace = torch.zeros(NWG * 16, dtype=torch.int64, device="cuda:0")
 
 SHAPES = [(96, 510, 128, False, "fwd"), (510, 96, 128, True, "fwd"), (96, 288, 128, False, "fwd"), (96, 96, 128, True, "fwd"),
           (96, 510, 64, False, "fwd"), (192, 1020, 32, False, "fwd"), (1020, 192, 32, True, "fwd"), (384, 2042, 16, False, "fwd")]
@@ -38,7 +38,7 @@ for cin, cout, S, res, mode in SHAPES:
     fn()
     torch.cuda.synchronize()
     lib.pir_x3_trace_set(None)
-    t = trace.cpu().numpy().reshape(-1, 8)
+    t = trace.cpu().numpy().reshape(-1, 16)
     t = t[t[:, 0] != 0]
     d = np.stack([t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 4] - t[:, 3], t[:, 4] - t[:, 0]], 1).astype(np.float64)
     life = (t[:, 6] - t[:, 5]).astype(np.float64) * 10.0          # ns
@@ -50,4 +50,9 @@ for cin, cout, S, res, mode in SHAPES:
     for i, nm in enumerate(names):
         v = d[:, i] / clk / 1e3
         print(f"    {nm:10s} mean {v.mean():7.2f} us   p10 {np.percentile(v, 10):7.2f}  p50 {np.percentile(v, 50):7.2f}  p90 {np.percentile(v, 90):7.2f}")
+    steps = np.maximum(t[:, 11].astype(np.float64), 1.0)
+    if t[:, 11].max() > 0:
+        ph = t[:, 8:11].astype(np.float64) / steps[:, None]
+        print(f"    per k-step of the main loop (cycles, wave 0): loads+reads+MFMA issue {ph[:, 0].mean():7.0f}   wait+split+LDS writes {ph[:, 1].mean():7.0f}"
+              f"   barrier {ph[:, 2].mean():7.0f}   (sum {ph.sum(1).mean():7.0f} = {ph.sum(1).mean()/clk/1e3:.2f} us)")
     sys.stdout.flush()
