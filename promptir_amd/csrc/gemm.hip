@@ -27,6 +27,7 @@ constexpr bool PIN_SCHED = PIR_PIN_SCHED;
 
 // tuning overrides (pir_tune_set): -1 / 0 = automatic
 int g_nn_cfg = -1, g_nt_cfg = -1, g_nt_splits = 0, g_nn_x3 = -1, g_nt_x3 = -1;
+int g_nt_quad = -1;   // knob 14: gemm_nt_x3 four-lanes-per-row stage loads (-1 automatic, 0 never, 1 always)
 
 __device__ __forceinline__ int c_row(int reg, int lane) { return pir_c_row(reg, lane); }
 
@@ -496,9 +497,13 @@ constexpr int X3_BK = 16;
 
 // waves_per_eu(3): three workgroups per CU (LDS allows it for every tile); the 128 x 128 tile would otherwise be
 // allocated 172 registers, four too many
-template <int TM, int TN, int WM, int WN, bool TAPS = false>
+// QUAD (plain operands only): four lanes read one row's 64 bytes of a stage (16 bytes each) and each lane splits and
+// stores its 4 pixels (8 bytes per piece), instead of two lanes x two 16-byte loads per row: one L1 request per row and
+// stage instead of two.
+template <int TM, int TN, int WM, int WN, bool TAPS = false, bool QUAD = false>
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(3)))
 void gemm_nt_x3_kernel(NTParams p) {
+  static_assert(!(TAPS && QUAD), "the tap-shifted operand keeps the fragment mapping");
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, T = WM * WN * 64;
   constexpr int XKS = BM + 4, YKS = BN + 4;            // 16-byte units between the two k-groups
   constexpr int XU = 2 * XKS, YU = 2 * YKS, PART = XU + YU, STAGE = 3 * PART;
@@ -529,7 +534,10 @@ void gemm_nt_x3_kernel(NTParams p) {
 
   constexpr int XF = 2 * BM, NX = (XF + T - 1) / T;    // fragments (8 pixels of one row) per stage
   constexpr int YF = 2 * BN, NY = (YF + T - 1) / T;
-  struct Stage { f32x4 x[NX][2]; f32x4 y[NY][2]; float ye[TAPS ? NY : 1]; int nb; };
+  constexpr int XQ = 4 * BM, NXQ = (XQ + T - 1) / T;   // QUAD: 4-pixel pieces per stage
+  constexpr int YQ = 4 * BN, NYQ = (YQ + T - 1) / T;
+  struct Stage { f32x4 x[QUAD ? 1 : NX][2]; f32x4 y[QUAD ? 1 : NY][2]; f32x4 xq[QUAD ? NXQ : 1]; f32x4 yq[QUAD ? NYQ : 1];
+                 float ye[TAPS ? NY : 1]; int nb; };
 
   auto load = [&](Stage& st) {   // loads the stage under the cursor, then advances it
     const int r = l_r;
@@ -538,6 +546,27 @@ void gemm_nt_x3_kernel(NTParams p) {
     if (++l_ch == p.chunks_per_r) { l_ch = 0; ++l_r; }
     const float* __restrict__ Xp = Xb + r * g.x_sr;
     const float* __restrict__ Yp = Yb + r * g.y_sr;
+    if constexpr (QUAD) {
+#pragma unroll
+      for (int q = 0; q < NXQ; ++q) {
+        const int f = tid + q * T;
+        int qd = f & 3, ii = f >> 2;
+        if (ii >= BM) { ii = 0; qd = 0; }
+        const int i = i0 + ii, ic = i < g.M1 ? i : g.M1 - 1;
+        const int n = nb + 4 * qd, nc = n < g.N ? n : g.N - 4;
+        st.xq[q] = *reinterpret_cast<const f32x4*>(Xp + ((long)ic * g.ldx + nc));
+      }
+#pragma unroll
+      for (int q = 0; q < NYQ; ++q) {
+        const int f = tid + q * T;
+        int qd = f & 3, jj = f >> 2;
+        if (jj >= BN) { jj = 0; qd = 0; }
+        const int j = j0 + jj, jc = j < g.M2 ? j : g.M2 - 1;
+        const int n = nb + 4 * qd, nc = n < g.N ? n : g.N - 4;
+        st.yq[q] = *reinterpret_cast<const f32x4*>(Yp + ((long)jc * g.ldy + nc));
+      }
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < NX; ++q) {
       const int f = tid + q * T;
@@ -583,6 +612,38 @@ void gemm_nt_x3_kernel(NTParams p) {
   auto stash = [&](int buf, const Stage& st) {
     pir_bf16x8* base = smem + buf * STAGE;
     const int nb = st.nb;
+    if constexpr (QUAD) {
+      pir_bf16x4* base4 = reinterpret_cast<pir_bf16x4*>(base);
+#pragma unroll
+      for (int q = 0; q < NXQ; ++q) {
+        const int f = tid + q * T;
+        const int qd = f & 3, ii = f >> 2;
+        if (XQ % T == 0 || f < XQ) {
+          const bool ok = i0 + ii < g.M1 && nb + 4 * qd < g.N;   // N % 4 == 0: a float4 is all-or-nothing
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ok ? st.xq[q][e] : 0.f;
+          const pir_frag3h fr = pir_split4(v);
+          const int u = 2 * ((qd >> 1) * XKS + ii) + (qd & 1);
+          base4[u] = fr.hi; base4[2 * PART + u] = fr.mid; base4[4 * PART + u] = fr.lo;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NYQ; ++q) {
+        const int f = tid + q * T;
+        const int qd = f & 3, jj = f >> 2;
+        if (YQ % T == 0 || f < YQ) {
+          const bool ok = j0 + jj < g.M2 && nb + 4 * qd < g.N;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ok ? st.yq[q][e] : 0.f;
+          const pir_frag3h fr = pir_split4(v);
+          const int u = 2 * (XU + (qd >> 1) * YKS + jj) + (qd & 1);
+          base4[u] = fr.hi; base4[2 * PART + u] = fr.mid; base4[4 * PART + u] = fr.lo;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < NX; ++q) {
       const int f = tid + q * T;
@@ -822,6 +883,13 @@ int launch_nt(NTParams& p, size_t ws_floats, int tap_sign, long g_st, hipStream_
       case 2: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 3, 4, 1, true>), grid, dim3(256), 0, s, p); break;
       default: hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2, 2, 2, true>), grid, dim3(256), 0, s, p); break;
     }
+  } else if (x3 && (g_nt_quad < 0 ? (g.N >= 1024 && pl.cfg != 1) : g_nt_quad != 0)) {   // sweep: tools/nt_quad_ab.py
+    switch (pl.cfg) {
+      case 0: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 1, 2, 2, false, true>), grid, dim3(256), 0, s, p); break;
+      case 1: hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 1, 2, 2, false, true>), grid, dim3(256), 0, s, p); break;
+      case 2: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 3, 4, 1, false, true>), grid, dim3(256), 0, s, p); break;
+      default: hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2, 2, 2, false, true>), grid, dim3(256), 0, s, p); break;
+    }
   } else if (x3) {
     switch (pl.cfg) {
       case 0: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 1, 2, 2>), grid, dim3(256), 0, s, p); break;   // 64 x 64
@@ -866,6 +934,7 @@ extern "C" int pir_tune_set(int knob, int value) {
     case 6: case 7: return pir_gdfn_wave_tune(knob, value);
     case 8: case 9: case 10: return pir_stencil_wave_tune(knob, value);
     case 13: return pir_ln_tune(knob, value);
+    case 14: g_nt_quad = value; return PIR_OK;
     default: return PIR_EINVAL;
   }
 }

@@ -85,6 +85,23 @@ __device__ __forceinline__ pir_frag3 pir_split8(const float (&v)[8]) {
   return f;
 }
 
+// the same split for 4 values (8 bytes per piece)
+typedef __bf16 pir_bf16x4 __attribute__((ext_vector_type(4)));
+struct pir_frag3h { pir_bf16x4 hi, mid, lo; };
+__device__ __forceinline__ pir_frag3h pir_split4(const float (&v)[4]) {
+  pir_frag3h f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float x = v[j];
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    f.hi[j] = h; f.mid[j] = m; f.lo[j] = (__bf16)r2;
+  }
+  return f;
+}
+
 // six-term product block: acc += (hi+mid+lo)_a x (hi+mid+lo)_b without the three <= 2^-27 terms
 __device__ __forceinline__ f32x16 pir_mfma_x3(const pir_bf16x8& ah, const pir_bf16x8& am, const pir_bf16x8& al,
                                               const pir_bf16x8& bh, const pir_bf16x8& bm, const pir_bf16x8& bl, f32x16 c) {

@@ -286,6 +286,27 @@ def test_gemm_nt_determinism_and_linearity():
     assert float((a.cpu().double().view(48, 48) - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("b,cin,cout,h,w", [(2, 48, 48, 20, 12), (3, 96, 254, 36, 36), (2, 127, 48, 32, 33 * 4), (1, 96, 510, 6, 22),
+                                            (2, 255, 96, 10, 106)])
+def test_gemm_nt_stage_load_mappings_agree(b, cin, cout, h, w):
+    """The four-lanes-per-row stage loads (knob 14 = 1) and the fragment loads (0) feed the same bf16x3 pieces to the same
+    MFMA sequence: results are bit-identical, on pixel counts with ragged 16-pixel tails and on every tile plan; both vs fp64."""
+    from promptir_amd import _lib, ops
+
+    dy, x = rnd("dy", b, cout, h, w).to(DEV), rnd("x", b, cin, h, w).to(DEV)
+    like = torch.empty(cout, cin, 1, 1, device=DEV)
+    try:
+        _lib.lib.pir_tune_set(14, 0)
+        frag = ops.conv1x1_wgrad(dy, x, like).clone()
+        _lib.lib.pir_tune_set(14, 1)
+        quad = ops.conv1x1_wgrad(dy, x, like).clone()
+    finally:
+        _lib.lib.pir_tune_set(14, -1)
+    assert torch.equal(frag, quad)
+    ref = torch.einsum("bmn,bkn->mk", dy.cpu().double().flatten(2), x.cpu().double().flatten(2))
+    assert float((quad.cpu().double().view(cout, cin) - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
 def test_l1_and_adamw():
     from promptir_amd import ops
 
