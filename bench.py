@@ -192,11 +192,12 @@ def main():
         trainer.prepare(x, t)      # back to the headline shape for the instrumented step below
 
     roofline, cpu = None, None
+    # one extra instrumented step: HIP events around every C-ABI call on the launch stream.  Every rank runs it (the
+    # step holds the gradient all-reduce, and the replicas must stay in step); rank 0 reports its own records.
+    ops.lib.start_timing()
+    trainer.train_step(x, t)
+    recs = ops.lib.stop_timing()
     if rank == 0:
-        # one extra instrumented step: HIP events around every C-ABI call on the launch stream
-        ops.lib.start_timing()
-        trainer.train_step(x, t)
-        recs = ops.lib.stop_timing()
         fam = {}
         for name, sec, work in recs:
             f = fam.setdefault(name, [0, 0.0, 0.0])

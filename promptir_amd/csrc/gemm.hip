@@ -14,6 +14,8 @@
 #include "gemm_common.h"
 #include <stdlib.h>
 
+extern int g_pir_skip_reduce;   // misc.hip (experiment knob 15)
+
 namespace {
 
 #ifndef PIR_BK
@@ -909,6 +911,7 @@ int launch_nt(NTParams& p, size_t ws_floats, int tap_sign, long g_st, hipStream_
   if (st) return st;
   const long per_split = (long)O * g.M1 * g.M2;
   const unsigned blocks = (unsigned)pir_cdiv(per_split, 64);
+  if ((g_pir_skip_reduce & 2) && O == 1) return PIR_OK;   // experiment: weight gradients only (the forward's gram has O > 1)
   if (pl.splits >= 64)
     hipLaunchKernelGGL((nt_reduce_kernel<16>), dim3(blocks), dim3(1024), 0, s, g.ws, pl.splits, per_split, g.M1, g.M2,
                        g.G, g.g_so, g.g_si, g.g_sj, g.alpha, g.accumulate, g_st);
@@ -935,6 +938,7 @@ extern "C" int pir_tune_set(int knob, int value) {
     case 8: case 9: case 10: return pir_stencil_wave_tune(knob, value);
     case 13: return pir_ln_tune(knob, value);
     case 14: g_nt_quad = value; return PIR_OK;
+    case 15: g_pir_skip_reduce = value; return PIR_OK;
     default: return PIR_EINVAL;
   }
 }

@@ -195,9 +195,12 @@ extern "C" int pir_add(const float* a, const float* b, float* out, long count, p
   return pir_launch_status();
 }
 
+int g_pir_skip_reduce = 0;   // experiment knob 15 (tools only): do not launch the small reduction kernels (wrong gradients)
+
 extern "C" int pir_reduce_partials(const float* parts, long stride, int S, float alpha, int accumulate,
                                    float* out, long count, pir_stream_t stream) {
   PIR_CHECK_ARG(parts && out && S > 0 && count > 0);
+  if (g_pir_skip_reduce & 1) return PIR_OK;
   const unsigned blocks = (unsigned)pir_cdiv(count, 64);
   if (S >= 64)
     hipLaunchKernelGGL((reduce_partials_kernel<16>), dim3(blocks), dim3(1024), 0, (hipStream_t)stream,

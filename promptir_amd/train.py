@@ -583,11 +583,16 @@ def init_distributed() -> tuple:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available() and os.environ.get("PIR_SHARE_GPU") == "1":
+        # rehearsal of the N>1 path on a box with fewer GPUs than ranks: ranks share devices (RCCL refuses that, so
+        # such a run also sets PIR_DIST_BACKEND=gloo; tests/test_drivers_gpu.py)
+        local = local % torch.cuda.device_count()
     if (world > 1 or os.environ.get("PIR_FORCE_PG") == "1") and not dist.is_initialized():   # PIR_FORCE_PG: 1-rank test
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("PIR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
+        if backend == "nccl":
             dist.init_process_group(backend, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)

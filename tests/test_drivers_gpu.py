@@ -84,6 +84,29 @@ def test_bench_runs_under_an_rccl_process_group():
     assert rec["config"]["step1_loss_check"]["ok"] is True
 
 
+def test_bench_with_two_ranks_sharing_the_gpu():
+    """bench.py exactly as the driver launches it for N=2 (torch.distributed.run, one process per rank), rehearsed on the one
+    GPU there is: both ranks use cuda:0 (PIR_SHARE_GPU=1) and, because RCCL refuses two ranks on one device, the gradient
+    all-reduces go over gloo (PIR_DIST_BACKEND=gloo).  Exercises what a 1-rank group cannot: rank-sharded batches, the
+    barrier + max-over-ranks timing, the segmented backward with a real exchange between replicas, every rank taking part
+    in every collective (including the instrumented step), the config-5 leg, rank 0 printing the one JSON line."""
+    import json
+
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                "--warmup", "1", "--batch", "4"],
+               {"PIR_SHARE_GPU": "1", "PIR_DIST_BACKEND": "gloo"}, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 only
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["process_group"] == "gloo" and rec["config"]["global_batch"] == 8
+    assert rec["scaling"] == "weak" and rec["value"] > 0 and rec["per_gpu_value"] * 2 == pytest.approx(rec["value"], rel=2e-2)
+    assert "overlapped" in rec["config"]["execution"]
+    assert rec["config5"] is not None and rec["config5"]["global_batch"] == 16
+    assert rec["roofline"]["achieved"] > 0 and rec["cpu_baseline"] is None     # cpu_baseline: N=1 only
+
+
 def test_train_cli_under_an_rccl_process_group(tmp_path):
     out = _run([sys.executable, os.path.join(ROOT, "train.py"), "--epochs", "3", "--batch_size", "4", "--synthetic", "8",
                 "--patch_size", "64", "--ckpt_dir", str(tmp_path / "ck"), "--start_epoch", "2", "--max_steps", "2"],
