@@ -537,8 +537,13 @@ int pir_nn_x3_plan(const pir_gemm_nn_t* a, int cfg) {
   // tile choice from the sweep in tools/ktune.py (PIR_X3=1): the 96 x 256 tile (1 KB contiguous per
   // row and stage) wins at the high-resolution levels even with up to ~13 % more padded rows.
   if (M <= 32) return 1214;
-  if (M <= 64) return g.K <= 64 ? 1222 : 2214;
+  if (M <= 64) return g.K <= 192 ? 1222 : 2214;   // 64 x 128 up to k = 192 (sweep of round 2: K = 127, 144 at M = 48)
   const long pad96 = pir_cdiv(M, 96) * 96, pad128 = pir_cdiv(M, 128) * 128;
+  // Low-resolution levels (32^2, 16^2: long k loops, few columns): the three-workgroups-per-CU tiles win by 6-12 %
+  // over 96 x 256 / 64 x 128 (tools/cfg_ab.py over every level, profiles/r02_gemm_nn_tile_sweep.txt): 96 x 128 unless
+  // 128-row tiles waste fewer rows (M = 510, 1020, 1021, 2042); also the 64^2 level's qkv (M = 288)
+  if (g.A3 && M >= 192 && g.N <= 1024) return pad128 < pad96 ? 2222 : 3114;
+  if (g.A3 && M >= 192 && g.N <= 4096 && g.K <= 128 && pad96 < pad128) return 3114;
   // Short k loops on long pixel rows (forward / input gradient of the 1x1 convolutions at the 128^2 and 64^2 levels,
   // HBM-bound): when 128-row tiles waste no more rows than 96-row tiles (M = 254, 255, 510), the 128 x 128 tile
   // (three workgroups per CU) is 5-11 % faster than 96 x 128 / 96 x 256 (tools/cfg_ab.py, round 2)

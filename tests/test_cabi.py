@@ -166,7 +166,13 @@ def test_gemm_plan_reaches_the_tuned_tiles_for_config3_shapes():
     assert plan(96, 510, 16384, 2) == 3114       # the test-sized batch takes the same branch
     assert plan(288, 96, 16384, 32) == 3214      # qkv: 96 x 256
     assert plan(48, 48, 16384, 32) == 1222
-    assert plan(48, 144, 16384, 32) == 2214
+    assert plan(48, 144, 16384, 32) == 1222      # 64 x 128 up to k = 192 ...
+    assert plan(48, 254, 16384, 32) == 2214      # ... 64 x 256 beyond
+    assert plan(576, 192, 1024, 32) == 3114      # low-resolution levels: 96 x 128 ...
+    assert plan(384, 2042, 256, 32) == 3114
+    assert plan(1020, 192, 1024, 32) == 2222     # ... unless 128-row tiles pad less
+    assert plan(2042, 384, 256, 32) == 2222
+    assert plan(288, 96, 4096, 32) == 3114       # level-2 qkv
     assert plan(96, 510, 16384, 32, presplit=False) != 3114   # the branch needs pre-split weights
     assert plan(0, 1, 1, 1) == -22
     # operands beyond the 32-bit byte offsets of the bf16x3 kernel fall back to the fp32 kernel

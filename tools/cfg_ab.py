@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gemm_nn tile-configuration sweep (knob 0) on the full-resolution / level-2 shapes: auto vs every fixed config."""
+"""gemm_nn tile-configuration sweep (knob 0) on the 1x1-convolution shapes of every level: auto vs every fixed config."""
 import os
 import sys
 
@@ -12,7 +12,10 @@ from tools.kbench import r, timeit  # noqa: E402
 B = int(os.environ.get("B", "32"))
 T = _lib.lib.pir_tune_set
 NAMES = {-1: "auto", 0: "32x256", 1: "64x256", 2: "96x256", 3: "128x128", 4: "64x128", 7: "96x128"}
-LEVELS = [("L1 enc C48 128^2", 48, 128), ("L1 dec C96 128^2", 96, 128), ("L2 C96 64^2", 96, 64)]
+LEVELS = [("L1 enc C48 128^2", 48, 128), ("L1 dec C96 128^2", 96, 128), ("L2 C96 64^2", 96, 64), ("L3 C192 32^2", 192, 32),
+          ("L4 C384 16^2", 384, 16), ("noise3 C704 16^2", 704, 16)]
+if os.environ.get("LEVELS"):
+    LEVELS = [LEVELS[int(i)] for i in os.environ["LEVELS"].split(",")]
 tot = {}
 for name, C, S in LEVELS:
     hid = int(C * 2.66)
