@@ -506,6 +506,13 @@ extern "C" int pir_split_bf16x3(const float* W, int M, int K, long sm, long sk, 
   return pir_launch_status();
 }
 
+int g_x3_narrow96 = 4;   // pir_tune_set knob 5: 96 x 128 instead of 96 x 256 below this many workgroups per CU
+
+int pir_nn_x3_tune(int knob, int value) {
+  if (knob == 5) { g_x3_narrow96 = value; return PIR_OK; }
+  return PIR_EINVAL;
+}
+
 // knob: -1 automatic, 0 never, 1 always
 bool pir_nn_x3_wanted(const pir_gemm_nn_t* a, int knob) {
   // measured (bench.py, batch 32): the bf16x3 path is at least as fast as fp32 MFMA for every gemm_nn of the
@@ -553,6 +560,8 @@ int pir_nn_x3_plan(const pir_gemm_nn_t* a, int cfg) {
   const bool use96 = g.N >= 1024 ? pad96 * 100 <= pad128 * 113 : pad96 < pad128;
   const long blocks = use96 ? pir_cdiv(M, 96) * pir_cdiv(g.N, 256) * batch : pir_cdiv(M, 128) * pir_cdiv(g.N, 128) * batch;
   if (blocks < 2L * PIR_NUM_CU && pir_cdiv(M, 64) * 64 <= pad128) return 1222;
+  // few 96 x 256 workgroups (one part-batch stream of the 64^2 level): 96 x 128 doubles them at three per CU
+  if (use96 && blocks < (long)g_x3_narrow96 * PIR_NUM_CU) return 3114;
   if (use96) return 3214;
   return 2222;
 }
