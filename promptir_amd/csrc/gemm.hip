@@ -937,7 +937,7 @@ extern "C" int pir_tune_set(int knob, int value) {
     case 5: return pir_nn_x3_tune(knob, value);
     case 6: case 7: return pir_gdfn_wave_tune(knob, value);
     case 8: case 9: case 10: return pir_stencil_wave_tune(knob, value);
-    case 13: return pir_ln_tune(knob, value);
+    case 13: case 16: return pir_ln_tune(knob, value);
     case 14: g_nt_quad = value; return PIR_OK;
     case 15: g_pir_skip_reduce = value; return PIR_OK;
     default: return PIR_EINVAL;

@@ -420,7 +420,13 @@ int ln_threads_for(int HW) { return HW >= 4096 ? 256 : (HW >= 1024 ? 128 : 64); 
 
 }  // namespace
 
-int pir_ln_tune(int knob, int value) { if (knob == 13) { g_ln_small = value; return PIR_OK; } return PIR_EINVAL; }
+int g_ln_bwd8 = -1;   // knob 16: eight waves per 64-pixel tile in the fused backward (half the registers per wave):
+                      // -1 automatic (C <= 64 or planes of <= 4096 pixels: -10..-15 %; +7 % at C = 96, 128^2), 0 never, 1 always
+int pir_ln_tune(int knob, int value) {
+  if (knob == 13) { g_ln_small = value; return PIR_OK; }
+  if (knob == 16) { g_ln_bwd8 = value; return PIR_OK; }
+  return PIR_EINVAL;
+}
 
 extern "C" int pir_reduce_partials(const float* parts, long stride, int S, float alpha, int accumulate,
                                    float* out, long count, pir_stream_t stream);
@@ -509,6 +515,7 @@ extern "C" int pir_layernorm_bwd(const float* dy, long dy_bs, const float* x, lo
 #define PIR_LNB(NR, WV) hipLaunchKernelGGL((ln_bwd_fused_kernel<NR, WV>), dim3((unsigned)S), dim3(LN_PIX * WV), 0, s, \
       dy, dy_bs, x, x_bs, weight, with_bias, mean, rstd, dx, dx_bs, dres, dres_bs, ws, B, C, HW, tiles)
     if (w16) { if (C <= 192) PIR_LNB(12, 16); else if (C <= 384) PIR_LNB(24, 16); else PIR_LNB(32, 16); }
+    else if ((g_ln_bwd8 < 0 ? (C <= 64 || HW <= 4096) : g_ln_bwd8 != 0) && C <= 128) { if (C <= 48) PIR_LNB(6, 8); else if (C <= 64) PIR_LNB(8, 8); else if (C <= 96) PIR_LNB(12, 8); else PIR_LNB(16, 8); }
     else if (C <= 48) PIR_LNB(12, 4); else if (C <= 64) PIR_LNB(16, 4); else if (C <= 96) PIR_LNB(24, 4); else PIR_LNB(32, 4);
 #undef PIR_LNB
     int st = pir_launch_status();

@@ -223,7 +223,10 @@ def test_fused_stencil_backwards(b, hid, h, w):
 
 @pytest.mark.parametrize("b,c,h,w,bias", [(2, 48, 8, 8, True), (1, 704, 4, 6, True), (2, 320, 3, 5, False),
                                           (1, 96, 16, 16, False), (2, 7, 9, 11, True), (2, 192, 32, 32, True),
-                                          (3, 384, 16, 16, False), (2, 160, 7, 9, True), (1, 768, 16, 16, True)])
+                                          (3, 384, 16, 16, False), (2, 160, 7, 9, True), (1, 768, 16, 16, True),
+                                          # the eight-wave fused backward (C <= 64, or planes of <= 4096 pixels in large batches)
+                                          (2, 48, 128, 128, True), (4, 64, 96, 100, False), (20, 96, 64, 64, True),
+                                          (18, 128, 64, 60, False), (17, 33, 64, 64, True)])
 def test_layernorm(b, c, h, w, bias):
     from oracle.promptir_ref import layer_norm
     from promptir_amd import ops

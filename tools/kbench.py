@@ -108,13 +108,13 @@ def bench_dw(B):
 
 def bench_ln(B):
     from promptir_amd import _lib
-    print("== LayerNorm (knob 13 = 0: 64-pixel tiles only; 1: 16-pixel tiles on small planes) ==")
+    print("== LayerNorm (knob 16 = 0: four waves per 64-pixel tile in the fused backward; 1: eight) ==")
     for name, C, S, heads in LEVELS + [("noise2 C320 32^2", 320, 32, 4)]:
       for knob in (0, 1):
-        _lib.lib.pir_tune_set(13, knob)
+        _lib.lib.pir_tune_set(16, knob)
         name_k = f"{name} k{knob}"
         bench_ln_one(name_k, B, C, S)
-    _lib.lib.pir_tune_set(13, 1)
+    _lib.lib.pir_tune_set(16, -1)
 
 
 def bench_ln_one(name, B, C, S):
