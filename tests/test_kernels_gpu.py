@@ -310,6 +310,32 @@ def test_gemm_nt_stage_load_mappings_agree(b, cin, cout, h, w):
     assert float((quad.cpu().double().view(cout, cin) - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
 
 
+def test_batched_weight_split_equals_the_single_weight_kernels():
+    """pir_split_bf16x3_batch (one launch for every registered weight, output-order walk) writes the same pieces as the
+    per-weight kernels, in forward, transposed (input-gradient) and nine-tap orientations, ragged M and K included."""
+    from promptir_amd import ops
+
+    ws = [rnd("w1", 70, 33, 1, 1).to(DEV), rnd("w2", 510, 96, 1, 1).to(DEV), rnd("w3", 48, 3, 3, 3).to(DEV),
+          rnd("w4", 96, 255, 1, 1).to(DEV), rnd("w5", 20, 37, 3, 3).to(DEV)]
+    first = []
+    for w in ws:
+        taps = w.shape[-1] == 3
+        for dgrad in (False, True):
+            buf, _ = ops._split_weight(w, dgrad=dgrad, taps=taps)       # first request: the single-weight kernel
+            first.append((buf, buf.clone()))
+    for w in ws:
+        w.add_(0.0)                                                      # bumps the version counter, same values
+    ops.refresh_split_weights()                                          # the batched kernel rewrites every buffer
+    torch.cuda.synchronize()
+    for buf, ref in first:
+        assert torch.equal(buf.view(torch.int16), ref.view(torch.int16))
+    for w in ws:                                                         # and the rewritten buffers are the registered ones
+        taps = w.shape[-1] == 3
+        for dgrad in (False, True):
+            buf, _ = ops._split_weight(w, dgrad=dgrad, taps=taps)
+            assert any(buf.data_ptr() == b.data_ptr() for b, _ in first)
+
+
 def test_l1_and_adamw():
     from promptir_amd import ops
 
