@@ -199,10 +199,12 @@ def main():
     recs = ops.lib.stop_timing()
     if rank == 0:
         fam = {}
-        for name, sec, work in recs:
-            f = fam.setdefault(name, [0, 0.0, 0.0])
-            f[0] += 1; f[1] += sec; f[2] += work
-        calls, secs, flops = fam.get("pir_gemm_nn", [0, 0.0, 0.0])
+        for name, sec, work, nbytes in recs:
+            f = fam.setdefault(name, [0, 0.0, 0.0, 0.0, 0.0])
+            f[0] += 1; f[1] += sec; f[2] += work; f[3] += nbytes
+            # this launch's own roofline time: the larger of its MFMA time (bf16x3 ceiling) and its HBM time
+            f[4] += max(work / (PEAK_BF16_MFMA_TFLOPS / X3_PASSES * 1e12), nbytes / (PEAK_HBM_GBS * 1e9))
+        calls, secs, flops, gemm_bytes, gemm_bound = fam.get("pir_gemm_nn", [0, 0.0, 0.0, 0.0, 0.0])
         total = sum(v[1] for v in fam.values())
         achieved = flops / secs / 1e12 if secs > 0 else 0.0
         x3 = ops.USE_X3 and os.environ.get("PIR_NN_X3", "1") != "0"
@@ -226,6 +228,10 @@ def main():
                     "peak_note": "algorithmic fp32-class flops; peak = 2500 TF/s dense bf16 / 6 MFMA passes per product"
                                  if x3 else "fp32 MFMA peak",
                     "vs_fp32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                    # the family mixes MFMA-bound and HBM-bound shapes: sum over launches of max(flops / MFMA ceiling,
+                    # algorithmic bytes / HBM peak) over the measured time, and the family's algorithmic byte rate
+                    "frac_of_per_launch_bound": round(gemm_bound / secs, 4) if secs > 0 else None,
+                    "algorithmic_gbs": round(gemm_bytes / secs / 1e9, 1) if secs > 0 else None, "hbm_peak_gbs": PEAK_HBM_GBS,
                     "launches_per_step": calls, "avg_launch_us": round(secs / max(calls, 1) * 1e6, 2),
                     "share_of_step_kernel_time": round(secs / total, 4) if total > 0 else None,
                     "families_ms": {k: round(v[1] * 1e3, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}}

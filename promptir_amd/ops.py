@@ -35,9 +35,22 @@ class _TimedLib:
         recs, self.records = self.records, None
         torch.cuda.synchronize()
         out = []
-        for name, start, end, work in recs:
-            out.append((name, start.elapsed_time(end) * 1e-3, work))
+        for name, start, end, work, nbytes in recs:
+            out.append((name, start.elapsed_time(end) * 1e-3, work, nbytes))
         return out
+
+    @staticmethod
+    def _bytes(name, args):
+        """Algorithmic HBM bytes of one call of the GEMM families (operands read once, result written once)."""
+        if name == "pir_gemm_nn":
+            g = args[0]._obj
+            o = g.O1 * g.O2
+            shared = g.a_s1 == 0 and g.a_s2 == 0
+            return 4.0 * o * (g.K * g.N + g.M * g.N * (2 if g.R else 1)) + 4.0 * g.M * g.K * (1 if shared else o)
+        if name == "pir_gemm_nt":
+            g = args[0]._obj
+            return 4.0 * g.O1 * g.O2 * g.BR * (g.M1 + g.M2) * g.N
+        return 0.0
 
     @staticmethod
     def _work(name, args):
@@ -66,7 +79,7 @@ class _TimedLib:
             start.record()
             status = fn(*args)
             end.record()
-            self.records.append((name, start, end, self._work(name, args)))
+            self.records.append((name, start, end, self._work(name, args), self._bytes(name, args)))
             return status
 
         return timed

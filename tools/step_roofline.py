@@ -59,7 +59,7 @@ recs = [r for r in ops.lib.stop_timing() if r[0] in ("pir_gemm_nn", "pir_gemm_nt
 raw.pir_gemm_nn, raw.pir_gemm_nt = orig_nn, orig_nt
 assert len(recs) == len(shapes), (len(recs), len(shapes))
 agg = {}
-for (name, sec, _), (key, flops, byts) in zip(recs, shapes):
+for (name, sec, _, _), (key, flops, byts) in zip(recs, shapes):
     a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
     a[0] += 1; a[1] += sec; a[2] += flops; a[3] += byts
 tot = {"nn": [0.0, 0.0], "nt": [0.0, 0.0]}
