@@ -74,7 +74,12 @@ def test_graph_and_part_streams_match_the_eager_step():
         assert np.allclose(losses, ref_losses, rtol=0, atol=2e-6), (losses, ref_losses)
         # fp32 re-association of the batch sum across the parts: a few ulp of the largest gradient entries
         assert float((grad - ref_grad).abs().max()) <= 5e-5 * float(ref_grad.abs().max())
-        assert float((param - ref_param).abs().max()) <= 2e-6
+        # AdamW's first steps move every entry by ~lr * sign(g): where a gradient entry is rounding noise around zero
+        # (the part batches pick other tile plans, hence another summation order) the sign, and with it a whole
+        # lr-sized step, may differ.  Such entries must stay a vanishing fraction and within the 3 steps' reach.
+        dp = (param - ref_param).abs()
+        assert float((dp > 2e-6).float().mean()) <= 1e-4, float((dp > 2e-6).float().mean())
+        assert float(dp.max()) <= 2 * 3 * 2e-4 * 1.01
 
 
 def _check_flat_grads(z, trainer):
