@@ -430,6 +430,8 @@ int pir_ln_tune(int knob, int value) {
 
 extern "C" int pir_reduce_partials(const float* parts, long stride, int S, float alpha, int accumulate,
                                    float* out, long count, pir_stream_t stream);
+int pir_reduce_partials_to2(const float* parts, long stride, int S, float alpha, int accumulate, float* out, float* out2,
+                            long split, long count, pir_stream_t stream);   // misc.hip
 
 extern "C" int pir_layernorm_fwd(const float* x, long x_bs, const float* weight, const float* bias,
                                  float* y, long y_bs, float* mean, float* rstd,
@@ -532,11 +534,9 @@ extern "C" int pir_layernorm_bwd(const float* dy, long dy_bs, const float* x, lo
     st = pir_launch_status();
     if (st) return st;
   }
-  // partials are [S][2][C]: reduce the two halves separately
-  int st = pir_reduce_partials(ws, 2L * C, S, 1.f, 0, dweight, C, stream);
-  if (st) return st;
-  if (with_bias) st = pir_reduce_partials(ws + C, 2L * C, S, 1.f, 0, dbias, C, stream);
-  return st;
+  // partials are [S][2][C]: one launch sums both halves, dweight from columns [0, C), dbias from [C, 2C)
+  if (with_bias) return pir_reduce_partials_to2(ws, 2L * C, S, 1.f, 0, dweight, dbias, C, 2L * C, stream);
+  return pir_reduce_partials(ws, 2L * C, S, 1.f, 0, dweight, C, stream);
 }
 
 extern "C" int pir_row_sumsq(const float* x, long x_bs, float* out, int B, int C, int HW, pir_stream_t stream) {

@@ -336,6 +336,27 @@ def test_batched_weight_split_equals_the_single_weight_kernels():
             assert any(buf.data_ptr() == b.data_ptr() for b, _ in first)
 
 
+@pytest.mark.parametrize("rows,count,stride", [(2048, 96, 192), (300, 48, 48), (64, 1000, 1000), (1000, 4590, 4590), (5, 33, 40),
+                                               (256, 1872, 2000), (4096, 17, 34)])
+def test_reduce_partials(rows, count, stride):
+    """Column sums of partial rows (every variant of the reduction kernel: few / many rows, few / many outputs),
+    with scale and accumulate, against fp64; deterministic."""
+    from promptir_amd import ops
+
+    parts = rnd("parts", rows, stride).to(DEV)
+    out = rnd("acc", count).to(DEV)
+    ref = out.cpu().double() + 0.5 * parts.cpu().double()[:, :count].sum(0)
+    first = out.clone()
+    ops.reduce_partials(parts, stride, rows, first, count, alpha=0.5, accumulate=True)
+    second = out.clone()
+    ops.reduce_partials(parts, stride, rows, second, count, alpha=0.5, accumulate=True)
+    assert torch.equal(first, second)
+    assert float((first.cpu().double() - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+    plain = torch.empty(count, device=DEV)
+    ops.reduce_partials(parts, stride, rows, plain, count)
+    assert float((plain.cpu().double() - parts.cpu().double()[:, :count].sum(0)).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+
+
 def test_l1_and_adamw():
     from promptir_amd import ops
 
