@@ -17,8 +17,10 @@ __device__ __forceinline__ float sum_parts(const float* __restrict__ p, int npar
 }
 
 // attn = softmax_j( gram[i][j] / (nq_i nk_j) * temperature ),  n* = max(sqrt(sumsq), eps)
-// 16 waves per map; a row (c <= 256 columns) is loaded ONCE into registers (the kernel is bound by the latency
-// of its dependent global loads, not by arithmetic), the column norms once per wave.
+// 16 waves per workgroup, ONE row per wave: the kernel is bound by the latency of its dependent global loads
+// (norm partials -> row -> exp -> store), so the rows of a map are spread over gridDim.y workgroups instead of being
+// walked six deep by one (10.7 -> ~5 us per launch at c = 96; B * heads is only 16 workgroups at the 128^2 level);
+// a row (c <= 256 columns) is loaded once into registers, the column norms once per wave.
 __global__ __launch_bounds__(1024) void mdta_softmax_fwd_kernel(const float* __restrict__ gram,
                                                                 const float* __restrict__ sumsq,
                                                                 const float* __restrict__ temperature,
@@ -37,7 +39,7 @@ __global__ __launch_bounds__(1024) void mdta_softmax_fwd_kernel(const float* __r
     const int j = lane + 64 * u;
     inv_k[u] = j < c ? 1.f / fmaxf(sqrtf(sum_parts(sk + j, nparts, 2 * C)), NORM_EPS) : 0.f;
   }
-  for (int i = wid; i < c; i += nw) {
+  for (int i = blockIdx.y * nw + wid; i < c; i += nw * gridDim.y) {
     const float inv_q = 1.f / fmaxf(sqrtf(sum_parts(sq + i, nparts, 2 * C)), NORM_EPS);
     float sv[MAXJ];
     float m = -INFINITY;
@@ -65,13 +67,14 @@ __global__ __launch_bounds__(1024) void mdta_softmax_fwd_kernel(const float* __r
 }
 
 // Backward through softmax, temperature and both L2 normalisations (see include/promptir_hip.h).
+// MAXJ: 64-column groups per lane (c <= 64 * MAXJ); ROWS: rows of a wave whose loads are in flight together.
+template <int MAXJ, int ROWS>
 __global__ __launch_bounds__(1024) void mdta_softmax_bwd_kernel(
     const float* __restrict__ dattn, const float* __restrict__ attn, const float* __restrict__ gram,
     const float* __restrict__ sumsq, const float* __restrict__ temperature, float* __restrict__ dgram,
     float* __restrict__ alpha_q, float* __restrict__ alpha_k, float* __restrict__ dtemp_partial, int heads, int c,
     int nparts) {
-  constexpr int MAXJ = 4;  // c <= 256 columns per lane-strided pass
-  __shared__ float colred[16][256];
+  __shared__ float colred[16][64 * MAXJ];
   __shared__ float red[16];
   const int bh = blockIdx.x, b = bh / heads, h = bh % heads, C = heads * c;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -91,36 +94,48 @@ __global__ __launch_bounds__(1024) void mdta_softmax_bwd_kernel(
     col[u] = 0.f;
   }
   float dt_acc = 0.f;
-  for (int i = wid; i < c; i += nw) {
-    const float sqi = sum_parts(sq + i, nparts, 2 * C);
-    const float nq = fmaxf(sqrtf(sqi), NORM_EPS);
-    const float inv_q = 1.f / nq;
-    float dot = 0.f, av[MAXJ], dav[MAXJ], gv[MAXJ];   // the row's three operands, loaded once
+  // ROWS rows per trip: the loads of all of them (norm partials, attn, dattn, gram) are in flight before the first
+  // reduction - the walk over a wave's rows is a chain of dependent load latencies otherwise
+  for (int i0 = wid; i0 < c; i0 += ROWS * nw) {
+    float sqi[ROWS], av[ROWS][MAXJ], dav[ROWS][MAXJ], gv[ROWS][MAXJ], dot[ROWS];
 #pragma unroll
-    for (int u = 0; u < MAXJ; ++u) {
-      const int j = lane + 64 * u;
-      av[u] = j < c ? A[i * c + j] : 0.f;
-      dav[u] = j < c ? dA[i * c + j] : 0.f;
-      gv[u] = j < c ? G[i * c + j] : 0.f;
-      dot += dav[u] * av[u];
-    }
-    dot = pir_wave_sum(dot);
-    float rowterm = 0.f;
+    for (int r = 0; r < ROWS; ++r) {
+      const int i = i0 + r * nw, ic = i < c ? i : i0;
+      sqi[r] = sum_parts(sq + ic, nparts, 2 * C);
+      dot[r] = 0.f;
 #pragma unroll
-    for (int u = 0; u < MAXJ; ++u) {
-      const int j = lane + 64 * u;
-      if (j < c) {
-        const float dS = av[u] * (dav[u] - dot);
-        const float R = gv[u] * inv_q * inv_k[u];
-        dt_acc += dS * R;
-        const float dR = t * dS;
-        dG[i * c + j] = dR * inv_q * inv_k[u];
-        rowterm += dR * R;
-        col[u] += dR * R;
+      for (int u = 0; u < MAXJ; ++u) {
+        const int j = lane + 64 * u;
+        av[r][u] = j < c ? A[ic * c + j] : 0.f;
+        dav[r][u] = j < c ? dA[ic * c + j] : 0.f;
+        gv[r][u] = j < c ? G[ic * c + j] : 0.f;
+        dot[r] += dav[r][u] * av[r][u];
       }
     }
-    rowterm = pir_wave_sum(rowterm);
-    if (lane == 0) alpha_q[(long)b * C + h * c + i] = sqrtf(sqi) > NORM_EPS ? -rowterm * inv_q * inv_q : 0.f;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const int i = i0 + r * nw;
+      if (i >= c) break;
+      const float nq = fmaxf(sqrtf(sqi[r]), NORM_EPS);
+      const float inv_q = 1.f / nq;
+      const float d = pir_wave_sum(dot[r]);
+      float rowterm = 0.f;
+#pragma unroll
+      for (int u = 0; u < MAXJ; ++u) {
+        const int j = lane + 64 * u;
+        if (j < c) {
+          const float dS = av[r][u] * (dav[r][u] - d);
+          const float R = gv[r][u] * inv_q * inv_k[u];
+          dt_acc += dS * R;
+          const float dR = t * dS;
+          dG[i * c + j] = dR * inv_q * inv_k[u];
+          rowterm += dR * R;
+          col[u] += dR * R;
+        }
+      }
+      rowterm = pir_wave_sum(rowterm);
+      if (lane == 0) alpha_q[(long)b * C + h * c + i] = sqrtf(sqi[r]) > NORM_EPS ? -rowterm * inv_q * inv_q : 0.f;
+    }
   }
 #pragma unroll
   for (int u = 0; u < MAXJ; ++u) colred[wid][lane + 64 * u] = col[u];
@@ -141,8 +156,8 @@ __global__ __launch_bounds__(1024) void mdta_softmax_bwd_kernel(
 extern "C" int pir_mdta_softmax_fwd(const float* gram, const float* sumsq, int nparts, const float* temperature,
                                     float* attn, int B, int heads, int c, pir_stream_t stream) {
   PIR_CHECK_ARG(gram && sumsq && temperature && attn && B > 0 && heads > 0 && c > 0 && c <= 256 && nparts > 0);
-  hipLaunchKernelGGL(mdta_softmax_fwd_kernel, dim3((unsigned)(B * heads)), dim3(1024), 0, (hipStream_t)stream,
-                     gram, sumsq, temperature, attn, heads, c, nparts);
+  hipLaunchKernelGGL(mdta_softmax_fwd_kernel, dim3((unsigned)(B * heads), (unsigned)pir_cdiv(c, 16)), dim3(1024), 0,
+                     (hipStream_t)stream, gram, sumsq, temperature, attn, heads, c, nparts);
   return pir_launch_status();
 }
 
@@ -152,7 +167,9 @@ extern "C" int pir_mdta_softmax_bwd(const float* dattn, const float* attn, const
                                     int B, int heads, int c, pir_stream_t stream) {
   PIR_CHECK_ARG(dattn && attn && gram && sumsq && temperature && dgram && alpha_q && alpha_k && dtemp_partial);
   PIR_CHECK_ARG(B > 0 && heads > 0 && c > 0 && c <= 256 && nparts > 0);
-  hipLaunchKernelGGL(mdta_softmax_bwd_kernel, dim3((unsigned)(B * heads)), dim3(1024), 0, (hipStream_t)stream,
-                     dattn, attn, gram, sumsq, temperature, dgram, alpha_q, alpha_k, dtemp_partial, heads, c, nparts);
+#define PIR_SMB(MJ, RW) hipLaunchKernelGGL((mdta_softmax_bwd_kernel<MJ, RW>), dim3((unsigned)(B * heads)), dim3(1024), 0, \
+      (hipStream_t)stream, dattn, attn, gram, sumsq, temperature, dgram, alpha_q, alpha_k, dtemp_partial, heads, c, nparts)
+  if (c <= 64) PIR_SMB(1, 4); else if (c <= 128) PIR_SMB(2, 6); else PIR_SMB(4, 3);
+#undef PIR_SMB
   return pir_launch_status();
 }
