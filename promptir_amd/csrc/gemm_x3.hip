@@ -84,7 +84,7 @@ struct X3Conv { int H, W, ksteps; unsigned magic_ks, magic_w; };
 // CONV (needs A_PRE, weights from pir_split_bf16x3_taps): the k loop also runs over the nine taps.
 // waves_per_eu: the 128-column tiles (<= 50 KB of LDS) fit three workgroups per CU once the compiler is told to
 // stay within 168 registers (it then also keeps the accumulators in VGPRs); the 256-column tiles run two.
-template <int TM, int TN, int WM, int WN, bool A_MFAST, bool A_PRE, bool CONV = false>
+template <int TM, int TN, int WM, int WN, bool A_MFAST, bool A_PRE, bool CONV = false, bool BREG = false>
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu((WM == 2 && WN == 2 && TM == 1 && A_PRE && X3_OCC4) ? 4 : ((WM == 2 && WN == 2 && (A_PRE || TM * TN <= 2)) || (TM == 3 && TN == 1 && A_PRE)) ? 3 : 2)))
 void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, T = WM * WN * 64;
@@ -131,9 +131,11 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int f = tid + i * T;
-    const int n = n0 + f % BN;
-    b_voff[i] = n * 4;
-    b_kg[i] = __builtin_amdgcn_readfirstlane(f / BN);   // BN is a multiple of 64: uniform per wave
+    // BREG (one wave owns all rows of its 32 columns): every lane loads its own MFMA B fragment - column lane & 31 of
+    // the wave's block, k-group lane >> 5 (folded into the lane offset) - which then never passes through LDS
+    const int n = BREG ? n0 + wn * 32 + (lane & 31) : n0 + f % BN;
+    b_voff[i] = BREG ? n * 4 + (lane >> 5) * 8 * (int)g.ldx * 4 : n * 4;
+    b_kg[i] = BREG ? 0 : __builtin_amdgcn_readfirstlane(f / BN);   // BN is a multiple of 64: uniform per wave
     b_taps[i] = 0;
     if (CONV) {  // bit t set: tap t of this pixel column lies inside the image
       const int hh = pir_fastdiv(n, cv.magic_w), ww = n - hh * cv.W;
@@ -215,7 +217,10 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
       }
     }
   };
+  static_assert(!BREG || (WM == 1 && TN == 1 && NB == 1 && !CONV), "B in registers: one wave per column block");
+  Frag3 bfr[2];   // BREG: the split B fragment of the stage in each LDS buffer's turn
   auto stash_b = [&](int buf, const Stage& st) {
+    if constexpr (BREG) { bfr[buf] = split8(st.b[0], true); return; }
     bf16x8* base = smem + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -261,7 +266,10 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) { ah[i] = ap[(X3_ABLATE & 64) ? 0 : i * 32]; am[i] = (X3_ABLATE & 64) ? ah[i] : ap[PART + i * 32]; al[i] = (X3_ABLATE & 64) ? ah[i] : ap[2 * PART + i * 32]; }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) { bh[j] = (X3_ABLATE & 64) ? ah[0] : bp[j * 32]; bm[j] = (X3_ABLATE & 64) ? ah[0] : bp[PART + j * 32]; bl[j] = (X3_ABLATE & 64) ? ah[0] : bp[2 * PART + j * 32]; }
+    for (int j = 0; j < TN; ++j) {
+      if constexpr (BREG) { bh[j] = bfr[buf].hi; bm[j] = bfr[buf].mid; bl[j] = bfr[buf].lo; }
+      else { bh[j] = (X3_ABLATE & 64) ? ah[0] : bp[j * 32]; bm[j] = (X3_ABLATE & 64) ? ah[0] : bp[PART + j * 32]; bl[j] = (X3_ABLATE & 64) ? ah[0] : bp[2 * PART + j * 32]; }
+    }
     // term-major order: consecutive MFMAs go to DIFFERENT accumulators (the per-accumulator order of the six
     // terms, hence the result, is unchanged).  Left accumulator-major, the compiler emits six back-to-back
     // dependent MFMAs per accumulator.
@@ -366,6 +374,9 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
 #endif
 }
 
+int g_x3_breg = -1;   // knob 18: activations stay in registers in the one-wave-per-column-block tile (96 x 128): -1 automatic
+                      // (planes of <= 4096 pixels: -2..-9 %, bit-identical; neutral to worse at 128^2), 0 never, 1 always
+
 template <int TM, int TN, int WM, int WN>
 int launch_cfg(const pir_gemm_nn_t& g, hipStream_t s, const X3Conv* conv = nullptr) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -373,6 +384,9 @@ int launch_cfg(const pir_gemm_nn_t& g, hipStream_t s, const X3Conv* conv = nullp
   dim3 grid((unsigned)tiles, (unsigned)(g.O1 * g.O2)), block(WM * WN * 64);
   X3Conv cv = {0, 0, 0, 0u, 0u};
   if (conv) hipLaunchKernelGGL((gemm_nn_x3_kernel<TM, TN, WM, WN, true, true, true>), grid, block, 0, s, g, *conv);
+  else if (g.A3 && (g_x3_breg < 0 ? g.N <= 4096 : g_x3_breg != 0) && WM == 1 && TN == 1) {
+    if constexpr (WM == 1 && TN == 1) hipLaunchKernelGGL((gemm_nn_x3_kernel<TM, TN, WM, WN, true, true, false, true>), grid, block, 0, s, g, cv);
+  }
   else if (g.A3) hipLaunchKernelGGL((gemm_nn_x3_kernel<TM, TN, WM, WN, true, true>), grid, block, 0, s, g, cv);
   else if (g.a_sm == 1) hipLaunchKernelGGL((gemm_nn_x3_kernel<TM, TN, WM, WN, true, false>), grid, block, 0, s, g, cv);
   else hipLaunchKernelGGL((gemm_nn_x3_kernel<TM, TN, WM, WN, false, false>), grid, block, 0, s, g, cv);
@@ -516,6 +530,7 @@ int g_x3_narrow96 = 4;   // pir_tune_set knob 5: 96 x 128 instead of 96 x 256 be
 
 int pir_nn_x3_tune(int knob, int value) {
   if (knob == 5) { g_x3_narrow96 = value; return PIR_OK; }
+  if (knob == 18) { g_x3_breg = value; return PIR_OK; }
   return PIR_EINVAL;
 }
 
