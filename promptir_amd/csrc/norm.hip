@@ -132,7 +132,8 @@ __global__ __launch_bounds__(LN_PIX* LN_WAVES) void ln_bwd_dx_kernel(
 // per-channel dweight / dbias sums of its pixels in registers; one shuffle reduction per channel at
 // the end gives this workgroup's partial row ws[block][2][C].  dy and x are read exactly once.
 template <int NREG, int WAVES>
-__global__ __launch_bounds__(LN_PIX* WAVES) void ln_bwd_fused_kernel(
+__global__ __launch_bounds__(LN_PIX* WAVES) __attribute__((amdgpu_waves_per_eu(WAVES == 8 && NREG == 12 ? 4 : 1, 8)))
+void ln_bwd_fused_kernel(
     const float* __restrict__ dy, long dy_bs, const float* __restrict__ x, long x_bs,
     const float* __restrict__ weight, int with_bias, const float* __restrict__ mean, const float* __restrict__ rstd,
     float* __restrict__ dx, long dx_bs, const float* __restrict__ dres, long dres_bs,
@@ -421,7 +422,8 @@ int ln_threads_for(int HW) { return HW >= 4096 ? 256 : (HW >= 1024 ? 128 : 64); 
 }  // namespace
 
 int g_ln_bwd8 = -1;   // knob 16: eight waves per 64-pixel tile in the fused backward (half the registers per wave):
-                      // -1 automatic (C <= 64 or planes of <= 4096 pixels: -10..-15 %; +7 % at C = 96, 128^2), 0 never, 1 always
+                      // -1 automatic (C <= 96, or planes of <= 4096 pixels: -5..-15 %; at C = 96 only once the variant is
+                      // held to 128 registers = two 8-wave workgroups per CU), 0 never, 1 always
 int pir_ln_tune(int knob, int value) {
   if (knob == 13) { g_ln_small = value; return PIR_OK; }
   if (knob == 16) { g_ln_bwd8 = value; return PIR_OK; }
@@ -517,7 +519,7 @@ extern "C" int pir_layernorm_bwd(const float* dy, long dy_bs, const float* x, lo
 #define PIR_LNB(NR, WV) hipLaunchKernelGGL((ln_bwd_fused_kernel<NR, WV>), dim3((unsigned)S), dim3(LN_PIX * WV), 0, s, \
       dy, dy_bs, x, x_bs, weight, with_bias, mean, rstd, dx, dx_bs, dres, dres_bs, ws, B, C, HW, tiles)
     if (w16) { if (C <= 192) PIR_LNB(12, 16); else if (C <= 384) PIR_LNB(24, 16); else PIR_LNB(32, 16); }
-    else if ((g_ln_bwd8 < 0 ? (C <= 64 || HW <= 4096) : g_ln_bwd8 != 0) && C <= 128) { if (C <= 48) PIR_LNB(6, 8); else if (C <= 64) PIR_LNB(8, 8); else if (C <= 96) PIR_LNB(12, 8); else PIR_LNB(16, 8); }
+    else if ((g_ln_bwd8 < 0 ? (C <= 96 || HW <= 4096) : g_ln_bwd8 != 0) && C <= 128) { if (C <= 48) PIR_LNB(6, 8); else if (C <= 64) PIR_LNB(8, 8); else if (C <= 96) PIR_LNB(12, 8); else PIR_LNB(16, 8); }
     else if (C <= 48) PIR_LNB(12, 4); else if (C <= 64) PIR_LNB(16, 4); else if (C <= 96) PIR_LNB(24, 4); else PIR_LNB(32, 4);
 #undef PIR_LNB
     int st = pir_launch_status();
