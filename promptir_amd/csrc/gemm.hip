@@ -29,6 +29,8 @@ constexpr bool PIN_SCHED = PIR_PIN_SCHED;
 
 // tuning overrides (pir_tune_set): -1 / 0 = automatic
 int g_nn_cfg = -1, g_nt_cfg = -1, g_nt_splits = 0, g_nn_x3 = -1, g_nt_x3 = -1;
+int g_nt_want_half = 5;   // knob 19: split-K workgroups per CU aimed at, in halves (bench sweep with two part-batch streams:
+                          // 2: 100.5 ms, 4: 99.4, 5: 99.4, 6: 99.7-100.3, 8: 101.0, 12: 102.2; one stream: 6 beats 4 by 0.5 ms)
 int g_nt_quad = -1;   // knob 14: gemm_nt_x3 four-lanes-per-row stage loads (-1 automatic, 0 never, 1 always)
 
 __device__ __forceinline__ int c_row(int reg, int lane) { return pir_c_row(reg, lane); }
@@ -854,7 +856,7 @@ NTPlan nt_plan(int M1, int M2, int N, int O, int BR, int bk = NT_BK) {
   const long tiles = pir_cdiv(M1, pl.bm) * pir_cdiv(M2, pl.bn) * O;
   pl.chunks_per_r = (int)pir_cdiv(N, bk);
   const long total = (long)BR * pl.chunks_per_r;
-  long want = 3L * PIR_NUM_CU / tiles;                   // all blocks resident at once (3 per CU): no second round
+  long want = (long)g_nt_want_half * PIR_NUM_CU / (2 * tiles);   // all blocks resident at once (2.5 per CU), no second round
   if (want < 1) want = 1;
   const long min_stages = 128 / bk;                       // at least 128 pixels per split (sweeps at batch 8 and 32, tools/ktune.py)
   long max_by_work = total / min_stages > 0 ? total / min_stages : 1;
@@ -953,6 +955,7 @@ extern "C" int pir_tune_set(int knob, int value) {
     case 13: case 16: return pir_ln_tune(knob, value);
     case 14: g_nt_quad = value; return PIR_OK;
     case 15: g_pir_skip_reduce = value; return PIR_OK;
+    case 19: g_nt_want_half = value; return PIR_OK;
     default: return PIR_EINVAL;
   }
 }
