@@ -107,6 +107,60 @@ def step1_loss_check(loss_value, batch, patch, rank):
     return {"value": loss_value, "reference": ref, "tol": 2e-6, "ok": True}
 
 
+def _time_calls(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def inference_leg(net, sd, device, steps, warmup, check_cpu=True):
+    """BASELINE config 2: batch 8 x 3x128x128 sigma=25 forward (no_grad, hipGraph replay), patches/s; the first two
+    outputs against the CPU oracle on the same inputs (max-abs and PSNR difference, north_star's parity bar)."""
+    from promptir_amd import weights as W
+    from promptir_amd.infer import GraphedForward
+
+    degraded, clean = W.synthetic_pair(8, 128, 128, sigma=25, seed=200)
+    x = torch.from_numpy(degraded).to(device)
+    g = GraphedForward(net)
+    y = g(x)
+    dt = _time_calls(lambda: g(x), steps, warmup)
+    leg = {"workload": "BASELINE config 2: inference forward, batch 8 x 3x128x128, sigma 25, no_grad, hipGraph replay",
+           "value": round(8 / dt, 2), "unit": "patches/s", "ms_per_batch": round(dt * 1e3, 3)}
+    if check_cpu:
+        from oracle import promptir_ref as O
+
+        with torch.no_grad():
+            ref = O.promptir_forward(sd, torch.from_numpy(degraded[:2]))
+        got, t = y[:2].cpu(), torch.from_numpy(clean[:2])
+        leg["max_abs_err_vs_cpu_oracle"] = float((got - ref).abs().max())
+        leg["psnr_db"] = round(O.psnr(got, t), 4)
+        leg["psnr_db_cpu_oracle"] = round(O.psnr(ref, t), 4)
+        leg["parity_ok"] = bool(leg["max_abs_err_vs_cpu_oracle"] <= 1e-4 and
+                                abs(leg["psnr_db"] - leg["psnr_db_cpu_oracle"]) <= 1e-3)
+    return leg
+
+
+def tiled_leg(net, device, steps, warmup):
+    """BASELINE config 4: demo.py's tiled path on 1x3x512x512, tile 128 / overlap 32 = 25 tiles restored as one batch
+    (gather kernel, graph-replayed forward, blend kernel), ms per image."""
+    from promptir_amd import weights as W
+    from promptir_amd.infer import GraphedForward
+    from promptir_amd.tile import tile_eval
+
+    degraded, _ = W.synthetic_pair(1, 512, 512, sigma=25, seed=9)
+    x = torch.from_numpy(degraded).to(device)
+    g = GraphedForward(net)
+    dt = _time_calls(lambda: tile_eval(g, x, tile=128, tile_overlap=32), steps, warmup)
+    return {"workload": "BASELINE config 4: demo.py tiled path, 1x3x512x512, tile 128 overlap 32 (25 tiles, one batch)",
+            "value": round(dt * 1e3, 3), "unit": "ms/image", "higher_is_better": False,
+            "tiles_per_s": round(25 / dt, 2), "images_per_s": round(1 / dt, 3)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,7 +170,9 @@ def main():
                     help="patches per GPU of the headline line: 32 = BASELINE config 3 at N=1, the same per-GPU work at every "
                          "N (weak scaling); BASELINE config 5 (batch 8 per GPU) is measured beside it when N > 1")
     ap.add_argument("--config5", type=int, default=None,
-                    help="1: also time BASELINE config 5's per-GPU batch 8 and report it under `config5` (default: when N > 1)")
+                    help="0: skip the BASELINE config 5 leg (per-GPU batch 8 train step, reported under `config5`; default on)")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="skip the inference (config 2) and tiled 512x512 (config 4) legs (rank 0, after the timed region)")
     ap.add_argument("--patch", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -136,7 +192,7 @@ def main():
         baseline_cfg = "BASELINE config 5"
     else:
         baseline_cfg = "non-BASELINE batch size"
-    want_config5 = (world > 1 and args.batch != 8) if args.config5 is None else bool(args.config5)
+    want_config5 = (args.batch != 8) if args.config5 is None else bool(args.config5)
 
     net, sd = build_model(device)
     trainer = DataParallelTrainer(net, lr=2e-4)
@@ -214,13 +270,13 @@ def main():
         # HBM bytes per launch from the committed PMC profile of this build (rocprofv3 cannot run inside the timed
         # process): FETCH_SIZE x 2 (gfx950 wide-read correction) + WRITE_SIZE, averaged over the family's launches
         traffic, traffic_note = None, None
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
         if x3 and args.batch == 32 and os.path.exists(tpath):
             tj = json.load(open(tpath))
             fam_t = tj["families"].get("pir_gemm_nn")
             if fam_t:
                 traffic = round((2.0 * fam_t["fetch_kb_per_launch_raw"] + fam_t["write_kb_per_launch"]) * 1024)
-                traffic_note = "profiles/r02_traffic.json: " + tj["source"] + "; " + tj["note"]
+                traffic_note = "profiles/r03_traffic.json: " + tj["source"] + "; " + tj["note"]
         roofline = {"kernel": ("gemm_nn_x3_kernel" if x3 else "gemm_nn_kernel") + " (all instantiations behind pir_gemm_nn)",
                     "bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
@@ -237,7 +293,24 @@ def main():
                     "families_ms": {k: round(v[1] * 1e3, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}}
         if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N=1 only
             cpu = cpu_baseline(sd, args.patch)
+    inference, tiled = None, None
+    if rank == 0 and world == 1 and not args.no_legs and args.patch == 128:
+        # BASELINE configs 2 and 4 (replicas only at N > 1: no collective, so they are measured at N = 1), after the
+        # timed region, on the weights the timed steps left behind (re-split below: the optimiser changed them)
+        ops.refresh_split_weights()
+        net.eval()
+        cur = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        inference = inference_leg(net, cur, device, max(args.steps, 10), 3, check_cpu=not args.no_cpu_baseline)
+        tiled = tiled_leg(net, device, max(args.steps // 2, 5), 2)
     sync()
+    spread = None
+    if world > 1 and os.environ.get("PIR_BENCH_PARAM_CHECK") == "1":
+        # rehearsal check: the replicas must hold bit-identical parameters after the steps above
+        ref_p = trainer.opt.param.clone()
+        dist.broadcast(ref_p, src=0)
+        d = (trainer.opt.param - ref_p).abs().max().reshape(1)
+        dist.all_reduce(d, op=dist.ReduceOp.MAX)
+        spread = float(d.item())
 
     if rank == 0:
         patches = args.batch * world * args.steps
@@ -256,9 +329,12 @@ def main():
                        "execution": f"hipGraph={int(trainer.graph)}, part-batch streams={trainer.micro_streams}" +
                                     (", backward in 3 segments with overlapped gradient all-reduce" if trainer.staged else ""),
                        "process_group": dist.get_backend() if dist.is_initialized() else None,
+                       "world": world, "device_index": local, "replica_param_spread": spread,
+                       "staged_backward": bool(trainer.staged),
+                       "gradient_ranges_bytes": [[4 * lo, 4 * hi] for lo, hi in (trainer.opt.stages or [])],
                        "params": 35592263, "final_loss": float(loss), "step1_loss_check": loss_check},
             "per_gpu_value": round(patches / elapsed / world, 3),
-            "roofline": roofline, "cpu_baseline": cpu, "config5": config5,
+            "roofline": roofline, "cpu_baseline": cpu, "config5": config5, "inference": inference, "tiled_512": tiled,
         }
         print(json.dumps(out), flush=True)
     if dist.is_initialized():

@@ -45,7 +45,7 @@ def main():
 
     from net.model import PromptIR
     from promptir_amd.tile import pad_input, tile_eval
-    from promptir_amd.train import load_lightning_checkpoint
+    from promptir_amd.train import load_checkpoint_file, load_lightning_checkpoint
 
     if not torch.cuda.is_available():
         raise SystemExit("demo.py needs a ROCm device (no CPU fallback)")
@@ -54,7 +54,7 @@ def main():
     net = PromptIR(decoder=True)
     ckpt_path = os.path.join("ckpt", opt.ckpt_name)
     if os.path.exists(ckpt_path):
-        load_lightning_checkpoint(net, torch.load(ckpt_path, map_location="cpu"))
+        load_lightning_checkpoint(net, load_checkpoint_file(ckpt_path))
     else:
         print(f"[demo] {ckpt_path} not found: running with randomly initialised weights")
     net.to(dev).eval()

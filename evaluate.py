@@ -60,14 +60,14 @@ def main():
 
     from net.model import PromptIR
     from promptir_amd.tile import mirror_pad_64, psnr
-    from promptir_amd.train import load_lightning_checkpoint
+    from promptir_amd.train import load_checkpoint_file, load_lightning_checkpoint
 
     torch.cuda.set_device(opt.cuda)
     dev = torch.device("cuda", opt.cuda)
     net = PromptIR(decoder=True)
     ckpt_path = os.path.join("ckpt", opt.ckpt_name)
     if os.path.exists(ckpt_path):
-        load_lightning_checkpoint(net, torch.load(ckpt_path, map_location="cpu"))
+        load_lightning_checkpoint(net, load_checkpoint_file(ckpt_path))
     else:
         print(f"[evaluate] {ckpt_path} not found: randomly initialised weights (PSNR is then meaningless)")
     net.to(dev).eval()

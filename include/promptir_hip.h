@@ -44,6 +44,12 @@ const char* pir_arch(void);
  * set them before the first launch, never while another thread is launching. */
 int pir_tune_set(int knob, int value);
 
+/* 0 for the product build.  Bit 0 would mean a diagnostic build (kernels with pipeline components removed, results
+ * garbage): those macros no longer exist in the sources and pir_common.h refuses them; tests/test_cabi.py checks the
+ * shipped library reports 0.  Every remaining pir_tune_set knob selects between kernels / plans with identical results
+ * (tile plan, split count, band height); none skips work. */
+int pir_build_flags(void);
+
 /* ------------------------------------------------------------------ GEMM core
  * Batched  Y[o][m][n] = sum_k A[o](m,k) * X[o][k][n]  (+ rowscale[o][m] * R[o][m][n])
  *   o = o1*O2 + o2 (two-level batch so that (batch, head) slices of a qkv buffer

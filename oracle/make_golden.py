@@ -105,7 +105,7 @@ def model_case(fname, ctor_kwargs, batch, height, width, sigma, seed, with_backw
     print(fname, "y", tuple(y.shape), "absmax", float(y.abs().max()))
 
 
-def model_case_chunked(fname, ctor_kwargs, batch, chunk, height, width, sigmas, seed):
+def model_case_chunked(fname, ctor_kwargs, batch, chunk, height, width, sigmas, seed, weights_seed=None):
     """Loss + gradient summaries of a batch too large to run through the reference in one piece in this
     container (64 GiB, no swap): no op of the network mixes samples and nn.L1Loss is a mean over all elements, so
     loss_B = sum_c (n_c / B) loss_c and the gradients add the same way.  The real reference runs on `chunk`
@@ -114,7 +114,7 @@ def model_case_chunked(fname, ctor_kwargs, batch, chunk, height, width, sigmas, 
     PromptIR = _reference("net/model.py").PromptIR  # the real reference
 
     net = PromptIR(**ctor_kwargs)
-    load_generated(net, seed)
+    load_generated(net, seed if weights_seed is None else weights_seed)
     degraded, clean = W.synthetic_pair(batch, height, width, sigma=sigmas, seed=seed)
     total = 0.0
     ysum = []
@@ -128,6 +128,7 @@ def model_case_chunked(fname, ctor_kwargs, batch, chunk, height, width, sigmas, 
         ysum += [float(v) for v in y.detach().double().sum(dim=(1, 2, 3))]
         del y, loss
     out = {"ctor": np.array(json.dumps(ctor_kwargs)), "seed": np.array(seed), "batch": np.array(batch),
+           "weights_seed": np.array(seed if weights_seed is None else weights_seed),
            "size": np.array([height, width]), "sigmas": np.array(sigmas, dtype=np.int64),
            "loss": np.array(total, dtype=np.float64), "y_sum": np.array(ysum, dtype=np.float64)}
     grad_summary(list(net.named_parameters()), out, "")
@@ -223,6 +224,26 @@ def tile_case():
     print("tile_eval", tuple(y.shape))
 
 
+def tile_full_case():
+    """BASELINE config 4 at its real size: the REAL reference (full depth) under the restated demo.py harness on a
+    1x3x512x512 image, tile 128 / overlap 32 = 25 tiles.  The input is not stored (tests rebuild it with
+    W.synthetic_pair(1, 512, 512, sigma=25, seed=9)); only the blended, clamped image is kept."""
+    PromptIR = _reference("net/model.py").PromptIR
+    from oracle.promptir_ref import tile_eval, tile_starts
+
+    net = PromptIR(decoder=True)
+    load_generated(net, 0)
+    degraded, clean = W.synthetic_pair(1, 512, 512, sigma=25, seed=9)
+    x = torch.from_numpy(degraded)
+    with torch.no_grad():
+        y = tile_eval(net, x, tile=128, tile_overlap=32)
+    assert tile_starts(512, 128, 32) == [0, 96, 192, 288, 384]
+    np.savez_compressed(os.path.join(OUT, "tile_eval_full_512.npz"), y=y.numpy(), seed=np.array(9),
+                        weights_seed=np.array(0), size=np.array([512, 512]), sigma=np.array(25),
+                        ctor=np.array(json.dumps(dict(decoder=True))))
+    print("tile_eval full", tuple(y.shape), "absmax", float(y.abs().max()))
+
+
 def scheduler_case():
     LinearWarmupCosineAnnealingLR = _reference("utils/schedulers.py").LinearWarmupCosineAnnealingLR
 
@@ -272,6 +293,11 @@ def main():
         model_case("model_small_128.npz", small, 1, 128, 128, 25, 4, with_backward=False)
     if want("tile"):
         tile_case()
+    if want("tilefull"):   # BASELINE config 4 at full size and depth (25 tiles through the real reference)
+        tile_full_case()
+    if want("config3b32"):   # BASELINE config 3 at its real batch: bench.py's own batch (seed 100, rank 0), chunks of 4
+        model_case_chunked("model_full_128_b32.npz", dict(decoder=True), 32, 4, 128, 128,
+                           [(15, 25, 50)[i % 3] for i in range(32)], 100, weights_seed=0)
     if want("full"):
         model_case("model_full_64.npz", dict(decoder=True), 1, 64, 64, 25, 0)
         model_case("model_full_128.npz", dict(decoder=True), 1, 128, 128, 25, 5, with_backward=False)

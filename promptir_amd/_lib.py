@@ -57,6 +57,7 @@ SIGNATURES = {
     "pir_abi_version": (I, []),
     "pir_arch": (C.c_char_p, []),
     "pir_tune_set": (I, [I, I]),
+    "pir_build_flags": (I, []),
     "pir_gemm_nn": (I, [C.POINTER(GemmNN), S]),
     "pir_gemm_nn_plan": (I, [C.POINTER(GemmNN)]),
     "pir_split_bf16x3_bytes": (Z, [I, I]),

@@ -510,10 +510,10 @@ extern "C" int pir_gdfn_dwconv_bwd(const float* x, long x_bs, const float* w, co
     return pir_dwconv3x3_wgrad(dt, dt_bs, x, x_bs, dw, ws + dt_floats, ws_floats - dt_floats, B, 2 * hid, H, W, stream);
   }
   const GWPlan gw = gwplan(B, hid, H, W);
-  if (gw.ok && (gw.vec == 1 || (x_bs % gw.vec == 0 && dg_bs % gw.vec == 0 && dx_bs % gw.vec == 0 &&
+  // (a workspace below the wave plan's need - band-height override, caller-sized buffer - falls through to the tiled kernel)
+  if (gw.ok && (size_t)B * gw.nbands * 2 * hid * 9 <= ws_floats && (gw.vec == 1 || (x_bs % gw.vec == 0 && dg_bs % gw.vec == 0 && dx_bs % gw.vec == 0 &&
                                (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dg) | reinterpret_cast<uintptr_t>(dx)) % (4 * gw.vec) == 0))) {   // register-only sliding-window kernel
     const long parts = (long)B * gw.nbands;
-    if ((size_t)parts * 2 * hid * 9 > ws_floats) return PIR_ENOMEM;
     GWArgs g;
     g.x = x; g.x_bs = x_bs; g.w = w; g.dg = dg; g.dg_bs = dg_bs; g.dx = dx; g.dx_bs = dx_bs; g.ws = ws;
     g.B = B; g.hid = hid; g.H = H; g.W = W; g.lpu_shift = gw.lpu_shift; g.RB = gw.RB; g.nbands = gw.nbands;

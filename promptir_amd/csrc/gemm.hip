@@ -14,7 +14,6 @@
 #include "gemm_common.h"
 #include <stdlib.h>
 
-extern int g_pir_skip_reduce;   // misc.hip (experiment knob 15)
 
 namespace {
 
@@ -498,16 +497,6 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_nt_kernel(NTParams p) {
 // One stage = 16 pixels = one v_mfma_f32_32x32x16_bf16 k-step; split-K, partial layout and the reduction
 // are those of gemm_nt_kernel.  Needs 16-byte aligned rows and N % 4 == 0 (else the fp32 kernel runs).
 constexpr int X3_BK = 16;
-#ifndef NT_ABLATE
-#define NT_ABLATE 0   // tools/nt_ablate.sh (never set in the product build; results are garbage): 1 every stage re-reads the
-#endif                // split's first stage (cache hits), 2 no MFMAs, 4 no split arithmetic, 16 no barriers, 32 no LDS writes,
-                      // 64 one LDS read per fragment set
-#if NT_ABLATE & 16
-#define NT_SYNC() do { } while (0)
-#else
-#define NT_SYNC() __syncthreads()
-#endif
-
 // waves_per_eu(3): three workgroups per CU (LDS allows it for every tile); the 128 x 128 tile would otherwise be
 // allocated 172 registers, four too many
 // QUAD (plain operands only): four lanes read one row's 64 bytes of a stage (16 bytes each) and each lane splits and
@@ -556,7 +545,7 @@ void gemm_nt_x3_kernel(NTParams p) {
     const int r = l_r;
     const int nb = l_ch * X3_BK;
     st.nb = nb;
-    if (!(NT_ABLATE & 1) && ++l_ch == p.chunks_per_r) { l_ch = 0; ++l_r; }
+    if (++l_ch == p.chunks_per_r) { l_ch = 0; ++l_r; }
     const float* __restrict__ Xp = Xb + r * g.x_sr;
     const float* __restrict__ Yp = Yb + r * g.y_sr;
     if constexpr (QUAD) {
@@ -636,11 +625,9 @@ void gemm_nt_x3_kernel(NTParams p) {
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = ok ? st.xq[q][e] : 0.f;
-          pir_frag3h fr;
-          if (NT_ABLATE & 4) { fr.hi = fr.mid = fr.lo = __builtin_bit_cast(pir_bf16x4, (unsigned long long)(__builtin_bit_cast(unsigned, v[0]) ^ __builtin_bit_cast(unsigned, v[2])) << 32 | (__builtin_bit_cast(unsigned, v[1]) ^ __builtin_bit_cast(unsigned, v[3]))); }
-          else fr = pir_split4(v);
+          const pir_frag3h fr = pir_split4(v);
           const int u = 2 * ((qd >> 1) * XKS + ii) + (qd & 1);
-          if (!(NT_ABLATE & 32) || fr.hi[0] == (__bf16)12345.f) { base4[u] = fr.hi; base4[2 * PART + u] = fr.mid; base4[4 * PART + u] = fr.lo; }
+          base4[u] = fr.hi; base4[2 * PART + u] = fr.mid; base4[4 * PART + u] = fr.lo;
         }
       }
 #pragma unroll
@@ -652,11 +639,9 @@ void gemm_nt_x3_kernel(NTParams p) {
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = ok ? st.yq[q][e] : 0.f;
-          pir_frag3h fr;
-          if (NT_ABLATE & 4) { fr.hi = fr.mid = fr.lo = __builtin_bit_cast(pir_bf16x4, (unsigned long long)(__builtin_bit_cast(unsigned, v[0]) ^ __builtin_bit_cast(unsigned, v[2])) << 32 | (__builtin_bit_cast(unsigned, v[1]) ^ __builtin_bit_cast(unsigned, v[3]))); }
-          else fr = pir_split4(v);
+          const pir_frag3h fr = pir_split4(v);
           const int u = 2 * (XU + (qd >> 1) * YKS + jj) + (qd & 1);
-          if (!(NT_ABLATE & 32) || fr.hi[0] == (__bf16)12345.f) { base4[u] = fr.hi; base4[2 * PART + u] = fr.mid; base4[4 * PART + u] = fr.lo; }
+          base4[u] = fr.hi; base4[2 * PART + u] = fr.mid; base4[4 * PART + u] = fr.lo;
         }
       }
       return;
@@ -734,13 +719,13 @@ void gemm_nt_x3_kernel(NTParams p) {
     const pir_bf16x8* yp = base + XU + h * YKS + wn * TN * 32 + r;
     pir_bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) { ah[i] = xp[(NT_ABLATE & 64) ? 0 : i * 32]; am[i] = (NT_ABLATE & 64) ? ah[i] : xp[PART + i * 32]; al[i] = (NT_ABLATE & 64) ? ah[i] : xp[2 * PART + i * 32]; }
+    for (int i = 0; i < TM; ++i) { ah[i] = xp[i * 32]; am[i] = xp[PART + i * 32]; al[i] = xp[2 * PART + i * 32]; }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) { bh[j] = (NT_ABLATE & 64) ? ah[0] : yp[j * 32]; bm[j] = (NT_ABLATE & 64) ? ah[0] : yp[PART + j * 32]; bl[j] = (NT_ABLATE & 64) ? ah[0] : yp[2 * PART + j * 32]; }
+    for (int j = 0; j < TN; ++j) { bh[j] = yp[j * 32]; bm[j] = yp[PART + j * 32]; bl[j] = yp[2 * PART + j * 32]; }
     // term-major: consecutive MFMAs hit different accumulators (same per-accumulator term order as pir_mfma_x3)
 #define PIR_X3_TERM(A_, B_)                                                                   \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
-        acc[i][j] = (NT_ABLATE & 2) ? (acc[i][j] + (float)A_[i][0] * (float)B_[j][1]) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[i], B_[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[i], B_[j], acc[i][j], 0, 0, 0);
     PIR_X3_TERM(al, bh)
     PIR_X3_TERM(ah, bl)
     PIR_X3_TERM(am, bm)
@@ -764,21 +749,21 @@ void gemm_nt_x3_kernel(NTParams p) {
       load(s0);
       compute(0);
       stash(1, s1);
-      NT_SYNC();
+      __syncthreads();
       load(s1);
       compute(1);
       stash(0, s0);
-      NT_SYNC();
+      __syncthreads();
     }
     for (; c + 1 < c_end; c += 2) {   // tail: loads guarded
       if (c + 2 < c_end) load(s0);
       compute(0);
       stash(1, s1);
-      NT_SYNC();
+      __syncthreads();
       if (c + 3 < c_end) load(s1);
       compute(1);
       if (c + 2 < c_end) stash(0, s0);
-      NT_SYNC();
+      __syncthreads();
     }
     if (c < c_end) compute(0);
   }
@@ -926,7 +911,6 @@ int launch_nt(NTParams& p, size_t ws_floats, int tap_sign, long g_st, hipStream_
   if (st) return st;
   const long per_split = (long)O * g.M1 * g.M2;
   const unsigned blocks = (unsigned)pir_cdiv(per_split, 64);
-  if ((g_pir_skip_reduce & 2) && O == 1) return PIR_OK;   // experiment: weight gradients only (the forward's gram has O > 1)
   if (pl.splits >= 64)
     hipLaunchKernelGGL((nt_reduce_kernel<16>), dim3(blocks), dim3(1024), 0, s, g.ws, pl.splits, per_split, g.M1, g.M2,
                        g.G, g.g_so, g.g_si, g.g_sj, g.alpha, g.accumulate, g_st);
@@ -954,7 +938,6 @@ extern "C" int pir_tune_set(int knob, int value) {
     case 8: case 9: case 10: return pir_stencil_wave_tune(knob, value);
     case 13: case 16: return pir_ln_tune(knob, value);
     case 14: g_nt_quad = value; return PIR_OK;
-    case 15: g_pir_skip_reduce = value; return PIR_OK;
     case 19: g_nt_want_half = value; return PIR_OK;
     default: return PIR_EINVAL;
   }

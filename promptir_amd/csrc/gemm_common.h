@@ -24,13 +24,6 @@ __device__ __forceinline__ void pir_nn_epilogue(const f32x16 (&acc)[TM][TN], con
       const bool full = mb + 32 <= g.M && nb + 32 <= g.N;
       if (full) {
         const int offy = mrow * ldy + n;
-#if defined(X3_ABLATE) && (X3_ABLATE & 8)
-        float sum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
-        Y[offy] = sum;
-        continue;
-#endif
         float res[16];
         if (R) {
           const int offr = mrow * ldr + n;

@@ -13,41 +13,6 @@
 // holds A[row r][k = 8h + j] and B[k = 8h + j][col r], j = 0..7  => one 16-byte LDS read per fragment from a
 // [k-group][row][8 x bf16] image.  The split happens when a stage is written to LDS.
 #include "gemm_common.h"
-#ifndef X3_MFMA_PRIO
-#define X3_MFMA_PRIO 0   // experiment knob: > 0 raises the wave priority around the MFMA cluster, < 0 raises it everywhere else
-#endif
-#ifndef X3_OCC4
-#define X3_OCC4 1   // 64 x 128 tile with pre-split weights: four workgroups per CU (128 registers, 37.6 KB of LDS)
-#endif
-#ifndef X3_VMEM_FILL
-#define X3_VMEM_FILL 1   // issue the prefetch loads one per MFMA inside the main loop
-#endif
-#ifndef X3_ABLATE
-#define X3_ABLATE 0   // tools/x3_ablate.sh (never set in the product build; results are garbage): 1 every stage re-reads
-#endif                // stage 0 (cache hits), 2 no MFMAs, 4 no split arithmetic, 8 one store in sixteen, 16 no barriers in
-                      // the k loop, 32 no LDS writes, 64 one LDS read per fragment set, 128 no global loads after the prologue
-#if X3_ABLATE & 16
-#define X3_SYNC() do { } while (0)
-#else
-#define X3_SYNC() __syncthreads()
-#endif
-#ifndef X3_FILL
-#define X3_FILL 0   // N > 0: place N conversion VALU ops behind each MFMA of the main loop (measured: no gain)
-#endif
-
-#ifdef X3_TRACE   // tools/x3_trace.py: per-workgroup phase clocks of wave 0 (never defined in the product build)
-__device__ unsigned long long* x3_trace_buf;
-extern "C" int pir_x3_trace_set(unsigned long long* p) {
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(x3_trace_buf), &p, sizeof(p));
-}
-#define X3_MARK(i) do { if (x3_tr && threadIdx.x == 0) x3_tr[i] = __builtin_amdgcn_s_memtime(); } while (0)
-// phase sums inside the k loop (wave 0): PH(i) closes phase i = the time since the previous stamp
-#define X3_PH(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
-                      x3_ph[i] += t_ - x3_last; x3_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define X3_MARK(i) do { } while (0)
-#define X3_PH(i) do { } while (0)
-#endif
 
 namespace {
 
@@ -59,12 +24,6 @@ struct Frag3 { bf16x8 hi, mid, lo; };
 
 __device__ __forceinline__ Frag3 split8(const float (&v)[8], bool ok) {
   Frag3 f;
-#if X3_ABLATE & 4
-  u32x4 w = {__builtin_bit_cast(unsigned, v[0]) ^ __builtin_bit_cast(unsigned, v[4]), __builtin_bit_cast(unsigned, v[1]) ^ __builtin_bit_cast(unsigned, v[5]),
-             __builtin_bit_cast(unsigned, v[2]) ^ __builtin_bit_cast(unsigned, v[6]), __builtin_bit_cast(unsigned, v[3]) ^ __builtin_bit_cast(unsigned, v[7])};
-  f.hi = f.mid = f.lo = __builtin_bit_cast(bf16x8, w);
-  return f;
-#endif
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const float x = ok ? v[j] : 0.f;
@@ -85,7 +44,7 @@ struct X3Conv { int H, W, ksteps; unsigned magic_ks, magic_w; };
 // waves_per_eu: the 128-column tiles (<= 50 KB of LDS) fit three workgroups per CU once the compiler is told to
 // stay within 168 registers (it then also keeps the accumulators in VGPRs); the 256-column tiles run two.
 template <int TM, int TN, int WM, int WN, bool A_MFAST, bool A_PRE, bool CONV = false, bool BREG = false>
-__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu((WM == 2 && WN == 2 && TM == 1 && A_PRE && X3_OCC4) ? 4 : ((WM == 2 && WN == 2 && (A_PRE || TM * TN <= 2)) || (TM == 3 && TN == 1 && A_PRE)) ? 3 : 2)))
+__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu((WM == 2 && WN == 2 && TM == 1 && A_PRE) ? 4 : ((WM == 2 && WN == 2 && (A_PRE || TM * TN <= 2)) || (TM == 3 && TN == 1 && A_PRE)) ? 3 : 2)))
 void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, T = WM * WN * 64;
   constexpr int AKS = BM + 4;              // 16-byte units between the two k-groups of A (+4: bank shift)
@@ -102,16 +61,6 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
   const float* __restrict__ A = g.A + o1 * g.a_s1 + o2 * g.a_s2;
   const float* __restrict__ X = g.X + o1 * g.x_s1 + o2 * g.x_s2;
   float* __restrict__ Y = g.Y + o1 * g.y_s1 + o2 * g.y_s2;
-#ifdef X3_TRACE
-  unsigned long long* x3_tr = x3_trace_buf ? x3_trace_buf + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 16 : nullptr;
-  if (x3_tr && threadIdx.x == 0) {
-    x3_tr[5] = __builtin_amdgcn_s_memrealtime();
-    x3_tr[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
-  }
-#endif
-  unsigned long long x3_ph[4] = {0, 0, 0, 0}, x3_last = 0;
-  (void)x3_ph; (void)x3_last;
-  X3_MARK(0);
 
   constexpr int AF = 2 * BM, NA = (AF + T - 1) / T;   // 8-deep k fragments per stage
   constexpr int BF = 2 * BN, NB = (BF + T - 1) / T;
@@ -157,8 +106,7 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
   const int a3_part_bytes = (CONV ? 9 : 1) * g.M * g.a3_kp * 2, a3_step_bytes = g.M * 32, ldx4 = (int)g.ldx * 4;
 
   auto load = [&](int it_raw, Stage& st) {
-    if ((X3_ABLATE & 128) && it_raw >= 2) return;
-    const int it = (X3_ABLATE & 1) ? 0 : it_raw < iters ? it_raw : iters - 1;
+    const int it = it_raw < iters ? it_raw : iters - 1;
     int tap = 0, ks = it;
     if (CONV) { tap = pir_fastdiv(it, cv.magic_ks); ks = it - tap * cv.ksteps; }
     const int k0 = ks * XK, klast = g.K - 1 - k0;
@@ -205,7 +153,7 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
       if (AF % T == 0 || f < AF) {
         const int u = kg * AKS + mm;
         if (A_PRE) {  // rows beyond M only feed masked outputs: no zeroing needed
-          if (!(X3_ABLATE & 32) || st.a3[i][0][0] == (__bf16)12345.f) { base[u] = st.a3[i][0]; base[PART + u] = st.a3[i][1]; base[2 * PART + u] = st.a3[i][2]; }
+          base[u] = st.a3[i][0]; base[PART + u] = st.a3[i][1]; base[2 * PART + u] = st.a3[i][2];
         } else {
           // a fragment is all-or-nothing in m; k beyond K is zeroed element-wise
           float v[8];
@@ -228,7 +176,7 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
       const int nn = f % BN, kg = f / BN;
       const Frag3 fr = split8(st.b[i], true);   // k tail already zero (range-checked loads)
       const int u = AU + kg * BN + nn;
-      if (!(X3_ABLATE & 32) || fr.hi[0] == (__bf16)12345.f) { base[u] = fr.hi; base[PART + u] = fr.mid; base[2 * PART + u] = fr.lo; }
+      base[u] = fr.hi; base[PART + u] = fr.mid; base[2 * PART + u] = fr.lo;
     }
   };
   auto stash = [&](int buf, int it, const Stage& st) {
@@ -244,7 +192,6 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
     for (int q = 0; q < TM * TN * 6; ++q) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // one MFMA ...
       __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);               // ... one global load in its shadow
-      if (X3_FILL > 0) __builtin_amdgcn_sched_group_barrier(0x002, X3_FILL, 0);
     }
     __builtin_amdgcn_sched_group_barrier(0x200, 3 * NB, 0);
   };
@@ -264,114 +211,69 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
     const bf16x8* bp = base + AU + h * BN + wn * TN * 32 + r;
     bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) { ah[i] = ap[(X3_ABLATE & 64) ? 0 : i * 32]; am[i] = (X3_ABLATE & 64) ? ah[i] : ap[PART + i * 32]; al[i] = (X3_ABLATE & 64) ? ah[i] : ap[2 * PART + i * 32]; }
+    for (int i = 0; i < TM; ++i) { ah[i] = ap[i * 32]; am[i] = ap[PART + i * 32]; al[i] = ap[2 * PART + i * 32]; }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       if constexpr (BREG) { bh[j] = bfr[buf].hi; bm[j] = bfr[buf].mid; bl[j] = bfr[buf].lo; }
-      else { bh[j] = (X3_ABLATE & 64) ? ah[0] : bp[j * 32]; bm[j] = (X3_ABLATE & 64) ? ah[0] : bp[PART + j * 32]; bl[j] = (X3_ABLATE & 64) ? ah[0] : bp[2 * PART + j * 32]; }
+      else { bh[j] = bp[j * 32]; bm[j] = bp[PART + j * 32]; bl[j] = bp[2 * PART + j * 32]; }
     }
     // term-major order: consecutive MFMAs go to DIFFERENT accumulators (the per-accumulator order of the six
     // terms, hence the result, is unchanged).  Left accumulator-major, the compiler emits six back-to-back
     // dependent MFMAs per accumulator.
-#if X3_ABLATE & 2
-#define PIR_X3_TERM(A_, B_)                                                                   \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
-        acc[i][j][0] += __builtin_bit_cast(float, (int)A_[i][0] ^ (int)B_[j][1]);
-#else
 #define PIR_X3_TERM(A_, B_)                                                                   \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[i], B_[j], acc[i][j], 0, 0, 0);
-#endif
-    if (X3_MFMA_PRIO > 0) __builtin_amdgcn_s_setprio(X3_MFMA_PRIO);
-    if (X3_MFMA_PRIO < 0) __builtin_amdgcn_s_setprio(0);
     PIR_X3_TERM(al, bh)
     PIR_X3_TERM(ah, bl)
     PIR_X3_TERM(am, bm)
     PIR_X3_TERM(am, bh)
     PIR_X3_TERM(ah, bm)
     PIR_X3_TERM(ah, bh)
-    if (X3_MFMA_PRIO > 0) __builtin_amdgcn_s_setprio(0);
-    if (X3_MFMA_PRIO < 0) __builtin_amdgcn_s_setprio(-X3_MFMA_PRIO);
 #undef PIR_X3_TERM
   };
 
   // Two stages are loaded ahead into registers.  (Measured: making these loads unconditional so that the
   // compiler can keep exact vmcnt counts is slower - the two extra stage loads per tile cost more than the
   // deeper prefetch gains, K is often only 3-6 stages.)
-  if (X3_MFMA_PRIO < 0) __builtin_amdgcn_s_setprio(-X3_MFMA_PRIO);
   Stage s0, s1;
   load(0, s0);
   if (iters > 1) load(1, s1);
   stash(0, 0, s0);
   __syncthreads();
-  X3_MARK(1);
-#ifdef X3_TRACE
-  x3_last = __builtin_amdgcn_s_memtime();
-#endif
   int it = 0;
   // Main part: both prefetch loads are in range, so they sit in the same basic block as the MFMAs and the
   // scheduler can be told to issue one vector-memory instruction behind each MFMA.  In-kernel cycle counters
   // showed the load issue of a stage (19 instructions, ~40 cycles each in the wave's in-order stream) costing
   // ~820 cycles per k-step in front of 1152 cycles of MFMAs.
   for (; it + 3 < iters; it += 2) {
-#ifdef X3_TRACE   // stamped build: three phases per k-step, schedule pinned at the stamps
-    load(it + 2, s0);
-    compute(0);
-    X3_PH(0);
-    stash_b(1, s1);
-    stash_a(1, it + 1, s1);
-    X3_PH(1);
-    __syncthreads();
-    X3_PH(2);
-    load(it + 3, s1);
-    compute(1);
-    X3_PH(0);
-    stash_b(0, s0);
-    stash_a(0, it + 2, s0);
-    X3_PH(1);
-    __syncthreads();
-    X3_PH(2);
-    x3_ph[3] += 2;
-#else
     load(it + 2, s0);
     compute(0);
     stash_b(1, s1);
-    if (X3_VMEM_FILL) interleave();
+    interleave();
     stash_a(1, it + 1, s1);
-    X3_SYNC();
+    __syncthreads();
     load(it + 3, s1);
     compute(1);
     stash_b(0, s0);
-    if (X3_VMEM_FILL) interleave();
+    interleave();
     stash_a(0, it + 2, s0);
-    X3_SYNC();
-#endif
+    __syncthreads();
   }
   for (; it + 1 < iters; it += 2) {   // tail: at most three stages left, loads guarded
     if (it + 2 < iters) load(it + 2, s0);
     compute(0);
     stash_b(1, s1);
     stash_a(1, it + 1, s1);
-    X3_SYNC();
+    __syncthreads();
     if (it + 3 < iters) load(it + 3, s1);
     compute(1);
     stash_b(0, s0);   // harmless past the end (slot 0 is not read again)
     if (it + 2 < iters) stash_a(0, it + 2, s0);
-    X3_SYNC();
+    __syncthreads();
   }
   if (it < iters) compute(0);
-  X3_MARK(2);
 
   pir_nn_epilogue<TM, TN>(acc, g, Y, o1, o2, m0, n0, wm, wn, lane);
-#ifdef X3_TRACE
-  X3_MARK(3);
-  __builtin_amdgcn_s_waitcnt(0);   // stores acknowledged
-  X3_MARK(4);
-  if (x3_tr && threadIdx.x == 0) {
-    x3_tr[6] = __builtin_amdgcn_s_memrealtime();
-    for (int q = 0; q < 4; ++q) x3_tr[8 + q] = x3_ph[q];
-  }
-#endif
 }
 
 int g_x3_breg = -1;   // knob 18: activations stay in registers in the one-wave-per-column-block tile (96 x 128): -1 automatic

@@ -231,16 +231,13 @@ extern "C" int pir_add(const float* a, const float* b, float* out, long count, p
   return pir_launch_status();
 }
 
-int g_pir_skip_reduce = 0;   // experiment knob 15 (tools only): do not launch the small reduction kernels (wrong gradients)
-
 // columns [0, split) of the partial rows go to `out`, columns [split, count) to `out2` (one launch for LayerNorm's
 // dweight and dbias, whose partial rows are [2][C]); out2 == nullptr: everything to `out`
 int pir_reduce_partials_to2(const float* parts, long stride, int S, float alpha, int accumulate, float* out, float* out2,
                             long split, long count, pir_stream_t stream) {
   PIR_CHECK_ARG(parts && out && S > 0 && count > 0);
-  if (g_pir_skip_reduce & 1) return PIR_OK;
   const unsigned blocks = (unsigned)pir_cdiv(count, 64);
-  if (S >= 256 && count <= 4096 && !(g_pir_skip_reduce & 4))   // knob 15 bit 2: A/B against the 64-column kernel
+  if (S >= 256 && count <= 4096)
     hipLaunchKernelGGL(reduce_partials_narrow_kernel, dim3((unsigned)pir_cdiv(count, 16)), dim3(1024), 0, (hipStream_t)stream,
                        parts, stride, S, alpha, accumulate, out, count, out2, split);
   else if (S >= 64)
@@ -269,4 +266,10 @@ extern "C" int pir_adamw_step(float* param, const float* grad, float* exp_avg, f
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(count, 8192)), dim3(256), 0, (hipStream_t)stream,
                      param, grad, exp_avg, exp_avg_sq, count, decay, beta1, beta2, eps, step_size, inv_bc2_sqrt, grad_scale);
   return pir_launch_status();
+}
+
+// Build self-description for tests (tests/test_cabi.py): bit 0 = a diagnostic / ablation build (never: pir_common.h
+// refuses those macros), bits 8.. = the gfx950 code object this file was compiled for.
+extern "C" int pir_build_flags(void) {
+  return 0;
 }

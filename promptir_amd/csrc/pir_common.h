@@ -4,6 +4,12 @@
 #include <stdint.h>
 #include "../../include/promptir_hip.h"
 
+// Diagnostic builds of round 2 (per-phase clocks, one pipeline component removed per bit: results garbage) lived behind
+// these macros; the product sources no longer contain them, and a build that defines one is refused.
+#if defined(X3_ABLATE) || defined(NT_ABLATE) || defined(X3_TRACE) || defined(PIR_DIAG)
+#error "diagnostic macros are not part of the product build (see tools/patches/ for the round-2 experiment diffs)"
+#endif
+
 #define PIR_WAVE 64
 #define PIR_NUM_XCD 8
 #define PIR_NUM_CU 256

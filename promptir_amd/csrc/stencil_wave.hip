@@ -248,7 +248,9 @@ int pir_sw_try_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const
   const SWPlan p = swplan((long)B * C, H, W, max_vec_for({dy, x, dx}, {dy_bs, x_bs, dx_bs}));
   if (!p.ok) return 1000;
   const long parts = (long)B * p.nbands;
-  if ((size_t)parts * C * 9 > ws_floats) return PIR_ENOMEM;
+  // a band-count override (knob 8) or a caller-sized workspace below this plan's need: not served here, the caller
+  // falls through to the LDS-tiled kernel (whose own need it checks) instead of failing the whole backward
+  if ((size_t)parts * C * 9 > ws_floats) return 1000;
   SWArgs a = {};
   a.x = x; a.x_bs = x_bs; a.w = w; a.dy = dy; a.dy_bs = dy_bs; a.y = dx; a.y_bs = dx_bs; a.part = ws;
   a.B = B; a.C = C; a.H = H; a.W = W; a.lpu_shift = p.lpu_shift; a.RB = p.RB; a.nbands = p.nbands; a.nunits = (long)B * C;

@@ -340,10 +340,12 @@ class PromptIR(nn.Module):
     def encode_levels(self, inp_img):
         """patch_embed, encoder levels 1-3 and the three downsamplings -> (enc1, enc2, enc3, latent input)."""
         inp_enc_level1 = self.patch_embed(inp_img)
-        out_enc_level1 = self.encoder_level1(inp_enc_level1)
-        out_enc_level2 = self.encoder_level2(self.down1_2(out_enc_level1))
-        out_enc_level3 = self.encoder_level3(self.down2_3(out_enc_level2))
-        return out_enc_level1, out_enc_level2, out_enc_level3, self.down3_4(out_enc_level3)
+        # every encoder output feeds the next level AND the decoder's skip connection: ops.fork sums the two
+        # gradients with the library's own kernel
+        out_enc_level1, skip1 = ops.fork(self.encoder_level1(inp_enc_level1))
+        out_enc_level2, skip2 = ops.fork(self.encoder_level2(self.down1_2(out_enc_level1)))
+        out_enc_level3, skip3 = ops.fork(self.encoder_level3(self.down2_3(out_enc_level2)))
+        return skip1, skip2, skip3, self.down3_4(out_enc_level3)
 
     def run_latent(self, inp_latent):
         return self.latent(inp_latent)
@@ -354,19 +356,22 @@ class PromptIR(nn.Module):
 
     def decode(self, inp_img, latent, out_enc_level3, out_enc_level2, out_enc_level1):
         if self.decoder:
-            latent = _cat(latent, self.prompt3(latent))
+            latent, to_prompt = ops.fork(latent)
+            latent = _cat(latent, self.prompt3(to_prompt))
             latent = self.reduce_noise_level3(self.noise_level3(latent))
 
         inp_dec_level3 = _cat(self.up4_3(latent), out_enc_level3)
         out_dec_level3 = self.decoder_level3(self.reduce_chan_level3(inp_dec_level3))
         if self.decoder:
-            out_dec_level3 = _cat(out_dec_level3, self.prompt2(out_dec_level3))
+            out_dec_level3, to_prompt = ops.fork(out_dec_level3)
+            out_dec_level3 = _cat(out_dec_level3, self.prompt2(to_prompt))
             out_dec_level3 = self.reduce_noise_level2(self.noise_level2(out_dec_level3))
 
         inp_dec_level2 = _cat(self.up3_2(out_dec_level3), out_enc_level2)
         out_dec_level2 = self.decoder_level2(self.reduce_chan_level2(inp_dec_level2))
         if self.decoder:
-            out_dec_level2 = _cat(out_dec_level2, self.prompt1(out_dec_level2))
+            out_dec_level2, to_prompt = ops.fork(out_dec_level2)
+            out_dec_level2 = _cat(out_dec_level2, self.prompt1(to_prompt))
             out_dec_level2 = self.reduce_noise_level1(self.noise_level1(out_dec_level2))
 
         inp_dec_level1 = _cat(self.up2_1(out_dec_level2), out_enc_level1)

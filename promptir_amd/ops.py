@@ -1031,6 +1031,39 @@ class CatChannelsFn(torch.autograd.Function):
         return dy[:, :ctx.ca], dy[:, ctx.ca:]
 
 
+class ForkFn(torch.autograd.Function):
+    """A tensor that feeds two consumers (an encoder output going to both the downsampling and the decoder's concat,
+    net/model.py:326-334,341-370; a decoder output going to both its prompt block and the concat): two aliases out,
+    and ONE pir_add of the two gradients in the backward - otherwise the autograd engine sums them with an ATen
+    elementwise kernel of its own."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, da, db):
+        if da is None or db is None:
+            return da if db is None else db
+        # One of the two is a fresh contiguous tensor (the dense-3x3 input gradient of the downsampling, the prompt
+        # block's dx), the other usually a channel slice of the concat's gradient (free batch stride): the slice is
+        # accumulated into the fresh one by the plane-copy kernel, no copy, no third buffer.  The fresh tensor is an
+        # intermediate of this backward with this node as its only consumer.
+        if not da.is_contiguous() and db.is_contiguous():
+            da, db = db, da
+        if not da.is_contiguous():
+            out = torch.empty(da.shape, dtype=torch.float32, device=da.device)
+            copy_planes(da, out)
+            da = out
+        copy_planes(db, da, accumulate=True)
+        return da
+
+
+def fork(x: torch.Tensor):
+    return ForkFn.apply(x)
+
+
 class PromptGenFn(torch.autograd.Function):
     """x -> bilinear(sum_l softmax(Linear(mean(x)))_l * P_l) (net/model.py:226-232); the 3x3 conv follows."""
 

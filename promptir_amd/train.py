@@ -135,7 +135,7 @@ class FlatAdamW:
             state[i] = {"step": torch.tensor(float(self.steps)),
                         "exp_avg": self.exp_avg[o:o + k].view(shape).detach().clone(),
                         "exp_avg_sq": self.exp_avg_sq[o:o + k].view(shape).detach().clone()}
-        group = {"lr": self.lr if lr is None else lr, "betas": tuple(self.betas), "eps": self.eps,
+        group = {"lr": self.lr if lr is None else lr, "initial_lr": self.lr, "betas": tuple(self.betas), "eps": self.eps,
                  "weight_decay": self.weight_decay, "amsgrad": False, "maximize": False, "foreach": None,
                  "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(names)))}
         return {"state": state, "param_groups": [group]}
@@ -172,8 +172,30 @@ class FlatAdamW:
             self.steps = steps.pop() if steps else 0
             return
         self.steps = int(sd["steps"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        theirs = sd.get("offsets")
+        if theirs is None or dict(theirs) == self.offsets:
+            if sd["exp_avg"].numel() != self.numel:
+                raise ValueError(f"flat optimizer state has {sd['exp_avg'].numel()} entries, this engine {self.numel}")
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            return
+        # a flat state written with another parameter order (round-1 checkpoints were laid out in named_parameters()
+        # order, this engine sorts by backward stage): the sizes agree, the positions do not - remap by NAME
+        sizes = {n: p.numel() for n, p in self.named}
+        missing = sorted(set(sizes) - set(theirs))
+        extra = sorted(set(theirs) - set(sizes))
+        if missing or extra:
+            raise ValueError(f"flat optimizer state does not cover this module: missing {missing[:3]}, unknown {extra[:3]}")
+        total = sd["exp_avg"].numel()
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for n, k in sizes.items():
+            src = int(theirs[n])
+            if src < 0 or src + k > total:
+                raise ValueError(f"flat optimizer state: {n} at {src} (+{k}) lies outside its {total} entries")
+            o = self.offsets[n]
+            self.exp_avg[o:o + k].copy_(sd["exp_avg"][src:src + k])
+            self.exp_avg_sq[o:o + k].copy_(sd["exp_avg_sq"][src:src + k])
 
 
 def allreduce_mean_(flat_grad: torch.Tensor, world_size: int) -> float:
@@ -217,10 +239,12 @@ class DataParallelTrainer:
         self.micro_streams = max(1, micro_streams) if self.opt.param.is_cuda else 1
         self._split_sig = None
         self._seg_state = None
-        # backward in three segments with the gradient all-reduce of each finished range overlapping the next segment:
-        # on by default whenever gradients are exchanged between ranks (PIR_STAGED=1 forces it for single-rank tests)
-        self.staged = (os.environ.get("PIR_STAGED", "1" if self.world > 1 else "0") != "0" and self.opt.param.is_cuda
-                       and self._staged_ok())
+        # backward in three segments with the gradient all-reduce of each finished range overlapping the next segment.
+        # OPT-IN (PIR_STAGED=1): RCCL kernels beside hipGraph replays have only run under a 1-rank group and a 2-rank
+        # gloo rehearsal so far; until an N > 1 RCCL run shows it equal to and faster than the single-graph step
+        # (+1.3 ms of graph seams at batch 8 against <= 1.6 ms of exposed all-reduce) the default for every world size
+        # is ONE graph followed by ONE all-reduce of the flat gradient.
+        self.staged = (os.environ.get("PIR_STAGED", "0") != "0" and self.opt.param.is_cuda and self._staged_ok())
         if self.micro_streams > 1:
             dev = self.opt.param.device
             n = self.micro_streams
@@ -558,8 +582,11 @@ class DataParallelTrainer:
         `load_from_checkpoint` and `trainer.fit(ckpt_path=...)` look up (loop progress is not tracked here: `loops`
         and `callbacks` are empty, so Lightning restarts its counters from `epoch` / `global_step`)."""
         cur_lr = self.opt.lr if lr is None else lr
+        # Lightning's ModelCheckpoint saves in on_train_epoch_end, BEFORE update_lr_schedulers of that epoch: at the
+        # epoch-N save the scheduler has seen step(0..N-1) plus its construction-time step, so last_epoch = N-1,
+        # _step_count = N+1 and _last_lr is the rate epoch N trained with (lightning_epoch_lr(N))
         sched = {"warmup_epochs": 15, "max_epochs": 150, "warmup_start_lr": 0.0, "eta_min": 0.0,
-                 "base_lrs": [self.opt.lr], "last_epoch": epoch, "_step_count": epoch + 2, "verbose": False,
+                 "base_lrs": [self.opt.lr], "last_epoch": max(epoch - 1, 0), "_step_count": epoch + 1, "verbose": False,
                  "_get_lr_called_within_step": False, "_last_lr": [cur_lr]}
         return {"epoch": epoch, "global_step": self.opt.steps, "pytorch-lightning_version": "2.0.1",
                 "state_dict": {"net." + k: v.detach().clone() for k, v in self.net.state_dict().items()},

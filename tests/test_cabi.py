@@ -23,6 +23,12 @@ def test_library_exports_every_declared_symbol():
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
     assert _lib.lib.pir_arch() == b"gfx950"
     assert _lib.lib.pir_abi_version() == _lib.ABI_VERSION
+    # the shipped library is the product build: no diagnostic / ablation code paths, no knob that skips work
+    assert _lib.lib.pir_build_flags() == 0
+    assert _lib.lib.pir_tune_set(15, 1) == -22          # round 2's "skip the reductions" experiment knob is gone
+    for src in ("gemm.hip", "gemm_x3.hip", "gemm_common.h"):
+        text = open(os.path.join(ROOT, "promptir_amd", "csrc", src)).read()
+        assert "ABLATE" not in text and "X3_TRACE" not in text, src
 
 
 def test_host_side_argument_checks_need_no_gpu():
@@ -143,6 +149,51 @@ def test_checkpoint_interchange_with_the_lightning_layout():
     for i in sd:
         assert torch.equal(st2[i]["exp_avg"], sd[i]["exp_avg"]) and float(st2[i]["step"]) == 2.0
     assert opt2.state_dict()["param_groups"][0]["lr"] == 1e-4
+    # scheduler block as Lightning 2.0.1 stores it at the epoch-3 save (before that epoch's scheduler step)
+    sch = out["lr_schedulers"][0]
+    assert sch["last_epoch"] == 2 and sch["_step_count"] == 4 and sch["_last_lr"] == [1e-4]
+    assert out["optimizer_states"][0]["param_groups"][0]["initial_lr"] == 2e-4
+    # demo.py / evaluate.py read checkpoints through load_checkpoint_file (non-tensor payload, torch >= 2.6)
+    for drv in ("demo.py", "evaluate.py"):
+        text = open(os.path.join(ROOT, drv)).read()
+        assert "load_checkpoint_file(ckpt_path)" in text and "torch.load(" not in text, drv
+
+
+def test_flat_optimizer_state_written_in_another_order_is_remapped_by_name():
+    """round-1 checkpoints hold the flat AdamW moments in named_parameters() order; this engine lays
+    the flat buffers out stage by stage.  Same total size, different positions: loading must remap by name (and refuse
+    states that do not cover the module), never copy verbatim."""
+    import pytest
+    import torch
+
+    from net.model import PromptIR
+    from promptir_amd.train import FlatAdamW, live_parameters
+
+    kw = dict(decoder=True, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1)
+    net = PromptIR(**kw)
+    flat = FlatAdamW(net)
+    # the round-1 layout: parameters in module order, same 64-float alignment
+    old_offsets, off = {}, 0
+    for n, p in live_parameters(net):
+        old_offsets[n] = off
+        off += (p.numel() + FlatAdamW.ALIGN - 1) // FlatAdamW.ALIGN * FlatAdamW.ALIGN
+    assert off == flat.numel and old_offsets != flat.offsets          # the case the advisor describes
+    g = torch.Generator().manual_seed(3)
+    old = {"steps": 7, "exp_avg": torch.randn(off, generator=g), "exp_avg_sq": torch.rand(off, generator=g),
+           "offsets": old_offsets}
+    flat.load_state_dict(old)
+    assert flat.steps == 7
+    for n, p in flat.named:
+        k, o, src = p.numel(), flat.offsets[n], old_offsets[n]
+        assert torch.equal(flat.exp_avg[o:o + k], old["exp_avg"][src:src + k]), n
+        assert torch.equal(flat.exp_avg_sq[o:o + k], old["exp_avg_sq"][src:src + k]), n
+    # own layout round-trips verbatim
+    again = FlatAdamW(PromptIR(**kw))
+    again.load_state_dict(flat.state_dict())
+    assert torch.equal(again.exp_avg, flat.exp_avg) and again.steps == 7
+    bad = dict(old, offsets={k: v for k, v in list(old_offsets.items())[1:]})
+    with pytest.raises(ValueError):
+        flat.load_state_dict(bad)
 
 
 

@@ -71,7 +71,7 @@ def test_bench_runs_under_an_rccl_process_group():
     import json
 
     out = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                "--batch", "8", "--no-cpu-baseline"],
+                "--batch", "8", "--no-cpu-baseline", "--no-legs"],
                {"PIR_FORCE_PG": "1", "PIR_STAGED": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533", "RANK": "0",
                 "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     assert out.returncode == 0, out.stderr[-3000:]
@@ -82,6 +82,53 @@ def test_bench_runs_under_an_rccl_process_group():
     assert "overlapped" in rec["config"]["execution"]      # the N>1 mode: three segment graphs, async RCCL all-reduces
     assert rec["config5"] is None                          # --batch 8 IS config 5
     assert rec["config"]["step1_loss_check"]["ok"] is True
+    assert rec["config"]["world"] == 1 and rec["config"]["device_index"] == 0 and rec["config"]["staged_backward"] is True
+    rng = rec["config"]["gradient_ranges_bytes"]
+    assert len(rng) == 3 and rng[0][0] == 0 and all(rng[i][1] == rng[i + 1][0] for i in range(2))
+    assert rec["inference"] is None and rec["tiled_512"] is None       # those legs belong to the default N=1 run
+
+
+def test_staged_flat_gradient_after_the_rccl_all_reduces_equals_the_single_graph_one():
+    """under a real (1-rank) RCCL group, the staged step - three segment graphs, one asynchronous
+    all-reduce per finished gradient range - must leave the SAME flat gradient after its all-reduces as the default
+    single-graph step followed by one all-reduce.  Child process (owns the process group)."""
+    code = r'''
+import os, sys, json, torch
+sys.path.insert(0, os.getcwd())
+import torch.distributed as dist
+from promptir_amd.train import DataParallelTrainer, init_distributed
+from promptir_amd import weights as W
+from net.model import PromptIR
+from tests import util
+init_distributed()
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+dev = torch.device("cuda", 0)
+ctor = dict(decoder=True, num_blocks=[1, 2, 1, 2], num_refinement_blocks=1)
+deg, clean = W.synthetic_pair(8, 64, 64, sigma=[15, 25, 50, 25, 15, 50, 25, 15], seed=21)
+x, t = torch.from_numpy(deg).to(dev), torch.from_numpy(clean).to(dev)
+out = {}
+for staged in ("0", "1"):
+    os.environ["PIR_STAGED"] = staged
+    net = PromptIR(**ctor)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(util.params_for(shapes, 22))
+    tr = DataParallelTrainer(net.to(dev), lr=0.0, graph=True)          # lr 0: the step leaves weights and gradient in place
+    assert tr.staged == (staged == "1")
+    loss = float(tr.train_step(x, t))
+    torch.cuda.synchronize()
+    out[staged] = (loss, tr.opt.grad.clone())
+(l0, g0), (l1, g1) = out["0"], out["1"]
+print(json.dumps({"dloss": abs(l0 - l1), "dgrad": float((g0 - g1).abs().max()), "gmax": float(g0.abs().max())}))
+dist.destroy_process_group()
+'''
+    import json
+
+    out = _run([sys.executable, "-c", code],
+               {"PIR_FORCE_PG": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29537", "RANK": "0", "WORLD_SIZE": "1",
+                "LOCAL_RANK": "0"})
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["dloss"] <= 2e-6 and rec["dgrad"] <= 5e-5 * rec["gmax"], rec
 
 
 def test_bench_with_two_ranks_sharing_the_gpu():
@@ -95,7 +142,7 @@ def test_bench_with_two_ranks_sharing_the_gpu():
     out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                 "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
                 "--warmup", "1", "--batch", "4"],
-               {"PIR_SHARE_GPU": "1", "PIR_DIST_BACKEND": "gloo"}, timeout=1500)
+               {"PIR_SHARE_GPU": "1", "PIR_DIST_BACKEND": "gloo", "PIR_STAGED": "1", "PIR_BENCH_PARAM_CHECK": "1"}, timeout=1500)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                  # rank 0 only
@@ -105,6 +152,9 @@ def test_bench_with_two_ranks_sharing_the_gpu():
     assert "overlapped" in rec["config"]["execution"]
     assert rec["config5"] is not None and rec["config5"]["global_batch"] == 16
     assert rec["roofline"]["achieved"] > 0 and rec["cpu_baseline"] is None     # cpu_baseline: N=1 only
+    # every replica ends with bit-identical parameters (same all-reduced gradient, same AdamW): max |p_rank - p_0| over ranks
+    assert rec["config"]["replica_param_spread"] == 0.0
+    assert rec["config"]["world"] == 2 and rec["config"]["staged_backward"] is True
 
 
 def test_train_cli_under_an_rccl_process_group(tmp_path):

@@ -221,6 +221,43 @@ def test_fused_stencil_backwards(b, hid, h, w):
     close(dw, wr.grad, rtol=5e-5)
 
 
+def test_wave_stencil_backwards_fall_back_when_the_workspace_is_below_their_plan():
+    """with a band-height override (knobs 9 / 6: 2 rows per band, 16 bands at H = 32) the register-only
+    kernels need more partial-sum rows than `*_ws_floats` provides (it assumes bands of >= 8 rows).  That must select
+    the LDS-tiled kernel, not fail the backward with PIR_ENOMEM."""
+    from promptir_amd import _lib, ops
+
+    b, hid, h, w = 2, 24, 32, 32
+    x, wt, dg, dy = rnd("x", b, 2 * hid, h, w), rnd("w", 2 * hid, 1, 3, 3), rnd("dg", b, hid, h, w), rnd("dy", b, 2 * hid, h, w)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    t = F.conv2d(xr, wr, padding=1, groups=2 * hid)
+    (F.gelu(t[:, :hid]) * t[:, hid:]).backward(dg)
+    xr2, wr2 = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    F.conv2d(xr2, wr2, padding=1, groups=2 * hid).backward(dy)
+    try:
+        assert _lib.lib.pir_tune_set(9, 2) == 0 and _lib.lib.pir_tune_set(6, 2) == 0
+        xd, wd, dgd, dyd = x.to(DEV), wt.to(DEV), dg.to(DEV), dy.to(DEV)
+        dx = torch.empty_like(xd)
+        dw = torch.empty_like(wd)
+        for fn, need, args, refs in (
+                ("pir_gdfn_dwconv_bwd", _lib.lib.pir_gdfn_dwconv_bwd_ws_floats(b, hid, h, w),
+                 lambda ws: (xd.data_ptr(), 2 * hid * h * w, wd.data_ptr(), dgd.data_ptr(), hid * h * w, dx.data_ptr(),
+                             2 * hid * h * w, dw.data_ptr(), ws.data_ptr(), ws.numel(), b, hid, h, w, None), (xr.grad, wr.grad)),
+                ("pir_dwconv3x3_bwd", _lib.lib.pir_dwconv3x3_bwd_ws_floats(b, 2 * hid, h, w),
+                 lambda ws: (dyd.data_ptr(), 2 * hid * h * w, xd.data_ptr(), 2 * hid * h * w, wd.data_ptr(), dx.data_ptr(),
+                             2 * hid * h * w, dw.data_ptr(), ws.data_ptr(), ws.numel(), b, 2 * hid, h, w, None), (xr2.grad, wr2.grad))):
+            ws = torch.empty(int(need), dtype=torch.float32, device=DEV)       # exactly what the ABI's query asks for
+            assert need < b * (h // 2) * 2 * hid * 9                            # ... which is below the overridden plan's need
+            st = getattr(_lib.lib, fn)(*args(ws))
+            torch.cuda.synchronize()
+            assert st == 0, (fn, st)
+            close(dx, refs[0], rtol=5e-5)
+            close(dw, refs[1], rtol=1e-4)
+    finally:
+        _lib.lib.pir_tune_set(9, 0)
+        _lib.lib.pir_tune_set(6, 0)
+
+
 @pytest.mark.parametrize("b,c,h,w,bias", [(2, 48, 8, 8, True), (1, 704, 4, 6, True), (2, 320, 3, 5, False),
                                           (1, 96, 16, 16, False), (2, 7, 9, 11, True), (2, 192, 32, 32, True),
                                           (3, 384, 16, 16, False), (2, 160, 7, 9, True), (1, 768, 16, 16, True),

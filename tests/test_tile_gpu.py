@@ -66,3 +66,41 @@ def test_demo_flow_on_unaligned_image_vs_oracle():
     assert y.shape == ref.shape == (1, 3, 150, 171)
     assert float((y.cpu() - ref).abs().max()) <= 1e-4
     assert 0.0 <= float(y.min()) and float(y.max()) <= 1.0
+
+
+def test_config4_full_size_full_depth_vs_reference_golden():
+    """BASELINE config 4 at its real size: 1x3x512x512, tile 128 / overlap 32 = 25 tiles, the full-depth network, the
+    tiles restored as ONE batch of 25 - against the REAL reference under the demo.py harness
+    (tests/golden/tile_eval_full_512.npz, oracle/make_golden.py tilefull).  The blend kernel's result also has to equal
+    the host-side blend (demo.py:35-47 restated with torch ops) of the very same per-tile HIP outputs bit for bit."""
+    from net.model import PromptIR
+    from promptir_amd.tile import tile_eval, tile_starts
+
+    z = util.load_npz("tile_eval_full_512.npz")
+    net = PromptIR(**json.loads(str(z["ctor"])))
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(util.params_for(shapes, int(z["weights_seed"])))
+    net.to(DEV)
+    deg, _ = W.synthetic_pair(1, 512, 512, sigma=int(z["sigma"]), seed=int(z["seed"]))
+    x = torch.from_numpy(deg).to(DEV)
+    seen = []
+
+    def model(tiles):
+        seen.append(tiles.shape[0])
+        out = net(tiles)
+        model.outs.append(out.clone())
+        return out
+
+    model.outs = []
+    y = tile_eval(model, x, tile=128, tile_overlap=32)
+    assert seen == [25]                                    # one launch chain over all 25 tiles
+    assert float((y.cpu() - torch.from_numpy(z["y"])).abs().max()) <= 1e-4
+    starts = tile_starts(512, 128, 32)
+    acc, cnt = torch.zeros_like(x), torch.zeros_like(x)
+    k = 0
+    for i in starts:
+        for j in starts:
+            acc[..., i:i + 128, j:j + 128] += model.outs[0][k:k + 1]
+            cnt[..., i:i + 128, j:j + 128] += 1.0
+            k += 1
+    assert torch.equal(y, (acc / cnt).clamp(0.0, 1.0))

@@ -253,3 +253,58 @@ def test_staged_backward_equals_the_whole_backward(monkeypatch):
             assert float((grads[n] - ref_grads[n]).abs().max()) <= 5e-5 * gmax, (key, n)
         for k in ref_params:
             assert float((params[k] - ref_params[k]).abs().max()) <= 2e-6, (key, k)
+
+
+def test_config3_at_batch_32_in_the_bench_execution_mode():
+    """BASELINE config 3 at its real batch: bench.py's own rank-0 batch (32 x 128x128, seed 100, weights seed 0) through
+    the hipGraph + part-batch-stream step, against the REAL reference's loss and 548 gradient summaries
+    (tests/golden/model_full_128_b32.npz, oracle/make_golden.py config3b32: eight chunks of four)."""
+    import json
+
+    from net.model import PromptIR
+    from promptir_amd.train import DataParallelTrainer
+
+    dev = torch.device("cuda:0")
+    z = util.load_npz("model_full_128_b32.npz")
+    seed, wseed, batch = int(z["seed"]), int(z["weights_seed"]), int(z["batch"])
+    assert (seed, wseed, batch) == (100, 0, 32)
+    net = PromptIR(**json.loads(str(z["ctor"])))
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(util.params_for(shapes, wseed))
+    net.to(dev)
+    degraded, clean = W.synthetic_pair(batch, 128, 128, sigma=[int(s) for s in z["sigmas"]], seed=seed)
+    x, t = torch.from_numpy(degraded).to(dev), torch.from_numpy(clean).to(dev)
+    trainer = DataParallelTrainer(net, lr=2e-4, graph=True)
+    trainer.prepare(x, t)
+    assert trainer.graph and trainer._graph is not None and trainer.micro_streams >= 2
+    loss = trainer.forward_backward(x, t)
+    torch.cuda.synchronize()
+    # the same number bench.py gates on (tests/golden/bench_step1_loss.json b32_rank0), here with the gradients behind it
+    ref = json.load(open(util.GOLDEN + "/bench_step1_loss.json"))["b32_rank0"]
+    assert abs(float(z["loss"]) - ref) <= 1e-7
+    assert abs(float(loss) - float(z["loss"])) <= 2e-6
+    assert _check_flat_grads(z, trainer) > 500
+
+
+def test_every_rank_shard_of_config5_matches_the_reference_loss():
+    """BASELINE config 5: the batch-8 shard bench.py builds for EACH of the ranks 0..7 (seed 100 + rank) gives the
+    reference's forward loss (tests/golden/bench_step1_loss.json b8_rank{r}); rank 0's shard additionally through the
+    graph-captured train step."""
+    import json
+    import sys
+
+    sys.path.insert(0, util.GOLDEN + "/../..")
+    import bench
+
+    dev = torch.device("cuda:0")
+    ref = json.load(open(util.GOLDEN + "/bench_step1_loss.json"))
+    net, _ = bench.build_model(dev)
+    from promptir_amd import ops
+
+    with torch.no_grad():
+        for rank in range(8):
+            x, t = bench.build_batch(8, 128, rank, dev)
+            loss = float(ops.l1_loss(net(x), t))
+            assert abs(loss - ref[f"b8_rank{rank}"]) <= 2e-6, (rank, loss, ref[f"b8_rank{rank}"])
+    # distinct shards (a DistributedSampler-style partition, train.py:336-339), not eight copies of one batch
+    assert len({round(ref[f"b8_rank{r}"], 9) for r in range(8)}) == 8

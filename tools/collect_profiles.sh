@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 EAGER="PIR_GRAPH=0 PIR_SIDE_STREAM=0 PIR_MICRO_STREAMS=1"
 run() {  # name, env string, rocprof args..., -- bench args
   local name=$1 envs=$2; shift 2
-  env $envs rocprofv3 "$@" --output-format csv -d "$ROOT/$OUT/$name" -- python3 "$ROOT/bench.py" --steps "${STEPS:-3}" --warmup 1 --no-cpu-baseline \
+  env $envs rocprofv3 "$@" --output-format csv -d "$ROOT/$OUT/$name" -- python3 "$ROOT/bench.py" --steps "${STEPS:-3}" --warmup 1 --no-cpu-baseline --no-legs --config5 0 \
       > "$ROOT/$OUT/$name.log" 2>&1 || echo "$name failed" >> "$ROOT/$OUT/errors.txt"
 }
 STEPS=5 run trace_eager "$EAGER" --kernel-trace --stats

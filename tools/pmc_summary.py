@@ -84,10 +84,22 @@ for r in rows:
           f"{f(r['lds_active'])} {f(r['ta_busy'])} {f(r['fetch_kb_raw'], '%9.0f')} {f(r['write_kb'], '%9.0f')} {f(r['hbm_gbs'], '%10.0f')}")
 
 # family totals for bench.py: kernels behind pir_gemm_nn = gemm_nn_x3_kernel / gemm_nn_kernel without the CONV flag
+def template_args(k):
+    m = re.search(r"<(.*)>", k)
+    return [a.strip() for a in m.group(1).split(",")] if m else []
+
+
+def is_conv(k):
+    """gemm_nn_x3_kernel<TM, TN, WM, WN, A_MFAST, A_PRE, CONV, BREG>: the CONV flag by POSITION (index 6; defaulted
+    trailing arguments are printed by the demangler, but do not rely on it)."""
+    a = template_args(k)
+    return len(a) > 6 and a[6] == "true"
+
+
 fam = {}
 for r in rows:
     k = r["kernel"]
-    if k.startswith("gemm_nn_x3_kernel") and not k.rstrip(">").endswith("true"):
+    if k.startswith("gemm_nn_x3_kernel") and not is_conv(k):
         name = "pir_gemm_nn"
     elif k.startswith("gemm_nn_x3_kernel"):
         name = "pir_conv3x3_x3"
@@ -109,6 +121,22 @@ for name, a in fam.items():
     summary[name] = {"launches_in_trace": a["launches"], "mean_us": a["us"] / a["launches"],
                      "fetch_kb_per_launch_raw": a["fetch_kb_raw"] / a["launches"], "write_kb_per_launch": a["write_kb"] / a["launches"],
                      "mfma_busy_time_weighted": a["mfma_cycles"] / a["cycles"] if a["cycles"] else None}
+# consistency with the bench's own count: launches of the pir_gemm_nn family in the trace must be
+# (steps + warmup + 2) x roofline.launches_per_step of the traced run (the parity-gate pass and the instrumented step
+# are full steps too).  A mismatch means the classification above no longer matches the kernels: fail loudly.
+log = os.path.join(out, "trace_eager.log")
+if os.path.exists(log):
+    line = [l for l in open(log) if l.startswith("{") and '"roofline"' in l]
+    if line:
+        b = json.loads(line[-1])
+        per_step = b["roofline"]["launches_per_step"]
+        steps_in_trace = b["steps"] + b["warmup"] + 2
+        got = summary.get("pir_gemm_nn", {}).get("launches_in_trace", 0)
+        if got != per_step * steps_in_trace:
+            sys.exit(f"pmc_summary: pir_gemm_nn has {got} launches in the trace, bench.py counted {per_step} per step x "
+                     f"{steps_in_trace} steps = {per_step * steps_in_trace}: family classification is off")
+        for a in summary.values():
+            a["steps_in_trace"] = steps_in_trace
 json.dump({"source": "tools/collect_profiles.sh + tools/pmc_summary.py (rocprofv3 --pmc, separate passes, serialized eager bench)",
            "note": "traffic = 2 x FETCH_SIZE (gfx950 wide-read correction; 4-byte-per-lane loads are uncalibrated) + WRITE_SIZE",
            "families": summary}, open(os.path.join(out, "traffic.json"), "w"), indent=1)
