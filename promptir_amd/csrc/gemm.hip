@@ -939,13 +939,17 @@ extern "C" int pir_tune_set(int knob, int value) {
     case 13: case 16: return pir_ln_tune(knob, value);
     case 14: g_nt_quad = value; return PIR_OK;
     case 19: g_nt_want_half = value; return PIR_OK;
+    case 20: return pir_nn_res_tune(knob, value);
+    case 21: case 22: case 23: return pir_nn_res_tune2(knob, value);
     default: return PIR_EINVAL;
   }
 }
 
 extern "C" int pir_gemm_nn_plan(const pir_gemm_nn_t* a) {
   if (!a || a->M <= 0 || a->K <= 0 || a->N <= 0 || a->O1 <= 0 || a->O2 <= 0) return PIR_EINVAL;
-  return pir_nn_x3_wanted(a, g_nn_x3) ? pir_nn_x3_plan(a, g_nn_cfg) : 0;
+  if (!pir_nn_x3_wanted(a, g_nn_x3)) return 0;
+  if (g_nn_cfg < 0 && pir_nn_res_wanted(a)) return 9000;   // resident-panel kernel (gemm_res.hip)
+  return pir_nn_x3_plan(a, g_nn_cfg);
 }
 
 extern "C" int pir_gemm_nn(const pir_gemm_nn_t* a, pir_stream_t stream) {
@@ -957,7 +961,13 @@ extern "C" int pir_gemm_nn(const pir_gemm_nn_t* a, pir_stream_t stream) {
   PIR_CHECK_ARG((long)a->M * a->ldy < 2147483647L && (long)a->K * a->ldx < 2147483647L);
   PIR_CHECK_ARG(a->R == nullptr || (long)a->M * a->ldr < 2147483647L);
   PIR_CHECK_ARG((long)(a->M - 1) * a->a_sm + (long)(a->K - 1) * a->a_sk < 2147483647L);
-  if (pir_nn_x3_wanted(a, g_nn_x3)) return pir_nn_x3_launch(a, g_nn_cfg, (hipStream_t)stream);
+  if (pir_nn_x3_wanted(a, g_nn_x3)) {
+    if (g_nn_cfg < 0) {   // long pixel streams against a weight panel that fits LDS: the resident-panel kernel
+      const int st = pir_nn_res_launch(a, (hipStream_t)stream);
+      if (st != 1000) return st;
+    }
+    return pir_nn_x3_launch(a, g_nn_cfg, (hipStream_t)stream);
+  }
   NNParams p;
   p.g = *a;
   p.taps = 1; p.flip = 0; p.H = 0; p.W = 0; p.a_st = 0;

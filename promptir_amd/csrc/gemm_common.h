@@ -112,3 +112,9 @@ bool pir_nn_x3_wanted(const pir_gemm_nn_t* a, int knob);
 int pir_nn_x3_launch(const pir_gemm_nn_t* a, int cfg, hipStream_t stream);
 int pir_nn_x3_plan(const pir_gemm_nn_t* a, int cfg);
 int pir_nn_x3_tune(int knob, int value);
+
+// resident-weight-panel persistent kernel (gemm_res.hip): 1000 = shape not served
+bool pir_nn_res_wanted(const pir_gemm_nn_t* a);
+int pir_nn_res_launch(const pir_gemm_nn_t* a, hipStream_t stream);
+int pir_nn_res_tune(int knob, int value);
+int pir_nn_res_tune2(int knob, int value);
