@@ -76,7 +76,8 @@ int pir_gemm_nn(const pir_gemm_nn_t* args, pir_stream_t stream);
 /* Host-only query: which kernel instantiation pir_gemm_nn would launch for `args` (pointers are not dereferenced
  * except A3 != NULL).  0 = plain fp32-MFMA kernel; otherwise the bf16x3 tile plan TM*1000 + TN*100 + WM*10 + WN
  * (workgroup of WM x WN waves, each TM x TN 32x32 MFMA tiles: 3114 = 96 x 128, 3214 = 96 x 256, 2222 = 128 x 128,
- * ...).  Negative on bad sizes.  Lets tests pin that a benchmarked shape reaches the instantiation tuned for it. */
+ * ...); 9000 = the persistent resident-weight-panel kernel, 9100 = the persistent B-stationary kernel (gemm_res.hip).
+ * Negative on bad sizes.  Lets tests pin that a benchmarked shape reaches the instantiation tuned for it. */
 int pir_gemm_nn_plan(const pir_gemm_nn_t* args);
 /* out[part][k/16][m][k%16] (bf16, k padded with zeros to kp = multiple of 16) = part-th piece of the exact
  * split W(m,k) = hi + mid + lo with W(m,k) = W[m*sm + k*sk]; out holds 3*M*kp bf16.  The 16 k-values of one

@@ -940,7 +940,7 @@ extern "C" int pir_tune_set(int knob, int value) {
     case 14: g_nt_quad = value; return PIR_OK;
     case 19: g_nt_want_half = value; return PIR_OK;
     case 20: return pir_nn_res_tune(knob, value);
-    case 21: case 22: case 23: return pir_nn_res_tune2(knob, value);
+    case 21: case 22: case 23: case 24: return pir_nn_res_tune2(knob, value);
     default: return PIR_EINVAL;
   }
 }
@@ -948,7 +948,10 @@ extern "C" int pir_tune_set(int knob, int value) {
 extern "C" int pir_gemm_nn_plan(const pir_gemm_nn_t* a) {
   if (!a || a->M <= 0 || a->K <= 0 || a->N <= 0 || a->O1 <= 0 || a->O2 <= 0) return PIR_EINVAL;
   if (!pir_nn_x3_wanted(a, g_nn_x3)) return 0;
-  if (g_nn_cfg < 0 && pir_nn_res_wanted(a)) return 9000;   // resident-panel kernel (gemm_res.hip)
+  if (g_nn_cfg < 0) {   // persistent kernels of gemm_res.hip: 9000 resident weight panel, 9100 B-stationary
+    const int kind = pir_nn_res_kind(a);
+    if (kind) return kind == 2 ? 9100 : 9000;
+  }
   return pir_nn_x3_plan(a, g_nn_cfg);
 }
 

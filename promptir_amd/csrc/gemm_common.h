@@ -114,7 +114,7 @@ int pir_nn_x3_plan(const pir_gemm_nn_t* a, int cfg);
 int pir_nn_x3_tune(int knob, int value);
 
 // resident-weight-panel persistent kernel (gemm_res.hip): 1000 = shape not served
-bool pir_nn_res_wanted(const pir_gemm_nn_t* a);
+int pir_nn_res_kind(const pir_gemm_nn_t* a);   // 0 not served, 1 resident-panel kernel, 2 B-stationary kernel
 int pir_nn_res_launch(const pir_gemm_nn_t* a, hipStream_t stream);
 int pir_nn_res_tune(int knob, int value);
 int pir_nn_res_tune2(int knob, int value);

@@ -283,6 +283,200 @@ void gemm_nn_res_kernel(ResArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// B-STATIONARY variant for tall weight matrices over short k (project_in / qkv forward, project_out input gradient at
+// the 128^2 and 64^2 levels: M = 255 .. 510 rows against K = 96).  In the row-tiled kernels every row tile splits the
+// same activations again (4 - 6 times at M = 510) and the conversion VALU work rivals the MFMA time (round-3 counters:
+// MFMA busy 0.44, VALU active 0.42).  Here a wave keeps the bf16x3 fragments of ITS 32-pixel column block for all of K
+// in registers (12 registers per 16-deep k-step) - split exactly once - and sweeps ALL output rows against them: the
+// pre-split weight rows stream through LDS in panels of 128 rows (double-buffered, one barrier per panel, loaded by the
+// whole workgroup from L2 while the previous panel is multiplied), two 32 x 32 output tiles at a time, each stored as
+// soon as its k loop ends.  Per column block: one split (~400 VALU operations) against 6 x KS x M/32 MFMAs, every
+// activation read from HBM exactly once, the output written once in 16-byte stores.
+struct BstArgs {
+  pir_gemm_nn_t g;
+  int nbpi; unsigned magic_nbpi; int blocks_total;
+  int per_wg;     // column blocks per workgroup (a multiple of 8: one per wave and round)
+  int panels;     // ceil(M / 128)
+};
+
+// NT: 32-row output tiles multiplied at a time (2 where registers allow: K = 48); TP: tiles per weight panel (3 or 4:
+// the panel height 32 TP is chosen for the fewest padded rows, 96 for M = 288)
+template <int KS, int NT, int TP>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
+void gemm_nn_bst_kernel(BstArgs p) {
+  constexpr int NW = 8, T = 512, BP = 32 * TP, KG = 2 * KS, PART = KG * BP, PANEL = 3 * PART;
+  constexpr int NLD = (PANEL + T - 1) / T;    // 16-byte units per thread and panel
+  __shared__ bf16x8 smem[2 * PANEL];
+  const pir_gemm_nn_t& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, r = lane & 31;
+  const int qk = ((r >> 4) << 2) | (r & 3), qj = (r >> 2) & 3;   // lane -> (pixel quad, row in quad group): res kernel
+  const int begin = blockIdx.x * p.per_wg;
+  const int end = begin + p.per_wg < p.blocks_total ? begin + p.per_wg : p.blocks_total;
+  const int rounds = (end - begin + NW - 1) / NW;
+  const int ldx4 = (int)g.ldx * 4, ldy = (int)g.ldy;
+  const unsigned xbytes = (unsigned)((((long)g.K - 1) * g.ldx + g.N) * 4);
+  const unsigned ybytes = (unsigned)((((long)g.M - 1) * g.ldy + g.N) * 4);
+  const __amdgpu_buffer_rsrc_t ars = pir_make_rsrc(g.A3, (unsigned)(6L * g.M * g.a3_kp));
+  const int part_bytes = g.M * g.a3_kp * 2;
+
+  // ---- weight panel `pi` (rows 128 pi ..): 16-byte unit (pass idx, thread) -> registers -> LDS buffer `buf`.
+  // Unit u = tid + 512 idx is (kg = u & 1, row = (u >> 1) % 128, c = (u >> 8) = part * KS + ks): row and kg depend on
+  // the lane only, c on the pass and on the workgroup half (waves 0-3 / 4-7) only - scalar arithmetic, two VGPRs.
+  const int p_kg = tid & 1, p_row = (tid >> 1) % BP;
+  // c = (u >> 1) / BP: BP = 128 makes it pass- and workgroup-half-uniform (scalar); BP = 96 needs the per-lane quotient
+  const int p_c0 = (tid >> 1) / BP;
+  auto panel_load = [&](int pi, int idx) {
+    const int c0 = BP == 128 ? __builtin_amdgcn_readfirstlane(p_c0) + 2 * idx : (tid + idx * T) / (2 * BP);
+    const int c = c0 < 3 * KS ? c0 : 0;                              // (a last pass may be partly empty)
+    const int ks = c % KS, part = c / KS;
+    const int row = BP == 128 ? p_row : ((tid + idx * T) >> 1) % BP;
+    const int m = pi * BP + row, mc = m < g.M ? m : g.M - 1;         // rows beyond M only feed dropped outputs
+    if constexpr (BP == 128)   // (part, k-step) uniform: scalar offset (rows are clamped, nothing relies on the range check)
+      return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+          ars, mc * 32 + p_kg * 16, part * part_bytes + ks * g.M * 32, 0));
+    else
+      return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+          ars, mc * 32 + p_kg * 16 + part * part_bytes + ks * g.M * 32, 0, 0));
+  };
+  auto panel_store = [&](int buf, int idx, const bf16x8& v) {
+    const int u = tid + idx * T;
+    const int c = BP == 128 ? __builtin_amdgcn_readfirstlane(p_c0) + 2 * idx : u / (2 * BP);
+    const int row = BP == 128 ? p_row : (u >> 1) % BP;
+    if (PANEL % T == 0 || c < 3 * KS) smem[buf * PANEL + c * 2 * BP + p_kg * BP + row] = v;
+  };
+
+  // ---- activations of a column block: 2 x 16-byte loads per k-step (see gemm_nn_res_kernel)
+  struct Cols { __amdgpu_buffer_rsrc_t rs; int vo; };
+  auto cols = [&](int b) {
+    Cols c;
+    const int o = pir_fastdiv(b, p.magic_nbpi), nb = (b - o * p.nbpi) * 32;
+    c.rs = pir_make_rsrc(g.X + (long)o * g.x_s1, xbytes);
+    c.vo = ((8 * h + qj) * (int)g.ldx + nb + 4 * qk) * 4;
+    return c;
+  };
+  f32x4 raw[KS][2];
+  auto load_raw = [&](int b) {
+    const Cols c = cols(b);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        raw[ks][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(c.rs, c.vo + (ks * 16 + 4 * t) * ldx4, 0, 0));
+  };
+
+  // first panel and first block
+  {
+#pragma unroll
+    for (int idx = 0; idx < NLD; ++idx) panel_store(0, idx, panel_load(0, idx));
+  }
+  int my = begin + wid;                       // this wave's column block in the current round
+  load_raw(my < end ? my : end - 1);
+  __syncthreads();
+
+  const bf16x8* ap0 = smem + h * BP + r;
+  int gp = 0;                                 // panels consumed so far: panel gp sits in buffer gp & 1
+  for (int round = 0; round < rounds; ++round, my += NW) {
+    const bool active = my < end;
+    // ---- this round's fragments: transpose + split, once
+    Frag3 bf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float v[8];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float a0 = raw[ks][t][0], a1 = raw[ks][t][1], a2 = raw[ks][t][2], a3 = raw[ks][t][3];
+        res_transpose4(a0, a1, a2, a3);
+        v[4 * t] = a0; v[4 * t + 1] = a1; v[4 * t + 2] = a2; v[4 * t + 3] = a3;
+      }
+      bf[ks] = res_split8(v);
+    }
+    const int o = pir_fastdiv(active ? my : end - 1, p.magic_nbpi), nb = ((active ? my : end - 1) - o * p.nbpi) * 32;
+    const __amdgpu_buffer_rsrc_t yrs = pir_make_rsrc(g.Y + (long)o * g.y_s1, active ? ybytes : 0u);   // idle wave: every store dropped
+    const int vy = ((4 * h + qj) * ldy + nb + 4 * qk) * 4;
+
+    for (int pi = 0; pi < p.panels; ++pi, ++gp) {
+      const int buf = gp & 1;
+      // (the panel after the very last one is loaded too - panel 0 once more, unused: keeps the pipeline free of branches,
+      // whose merges would make every wait a full drain)
+      const int nxt = pi + 1 < p.panels ? pi + 1 : 0;
+      if (pi + 1 == p.panels && round + 1 < rounds) {
+        __builtin_amdgcn_sched_barrier(0);
+        load_raw(my + NW < end ? my + NW : end - 1);                  // next round's activations fly during the last panel
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const bf16x8* ap = ap0 + buf * PANEL + (gp >> 30);
+      // (4 / NT) x KS iterations (TP / NT groups of NT 32-row tiles x k-steps), software-pipelined: iteration j multiplies with the
+      // weight fragments read during j - 1, reads those of j + 1, issues the load of one 16-byte unit of the NEXT panel
+      // and writes the unit issued PD iterations earlier into the other LDS buffer.
+      constexpr int NIT = (TP / NT) * KS;
+      constexpr int PD = NIT / 2;   // iterations between the load of a panel unit and its LDS write (an L2 round trip under load)
+      bf16x8 ah[NT], am[NT], al[NT];
+      auto read_a = [&](int j) {
+        const int pair = j / KS, ks = j % KS;
+#pragma unroll
+        for (int e = 0; e < NT; ++e) {
+          const int off = ks * 2 * BP + (NT * pair + e) * 32;
+          ah[e] = ap[off]; am[e] = ap[PART + off]; al[e] = ap[2 * PART + off];
+        }
+      };
+      read_a(0);
+      bf16x8 stage[NLD];
+      f32x16 acc[NT];
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int ks = j % KS;
+        if (ks == 0) {
+#pragma unroll
+          for (int e = 0; e < NT; ++e)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[e][q] = 0.f;
+        }
+        if (j < NLD) stage[j] = panel_load(nxt, j);
+        if (j >= PD && j - PD < NLD) panel_store(buf ^ 1, j - PD, stage[j - PD]);
+        bf16x8 ch[NT], cm[NT], cl[NT];
+#pragma unroll
+        for (int e = 0; e < NT; ++e) { ch[e] = ah[e]; cm[e] = am[e]; cl[e] = al[e]; }
+        if (j + 1 < NIT) read_a(j + 1);
+#define PIR_BST_TERM(A_, B_) \
+        _Pragma("unroll") for (int e = 0; e < NT; ++e) \
+            acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[e], B_, acc[e], 0, 0, 0);
+        PIR_BST_TERM(cl, bf[ks].hi)
+        PIR_BST_TERM(ch, bf[ks].lo)
+        PIR_BST_TERM(cm, bf[ks].mid)
+        PIR_BST_TERM(cm, bf[ks].hi)
+        PIR_BST_TERM(ch, bf[ks].mid)
+        PIR_BST_TERM(ch, bf[ks].hi)
+#undef PIR_BST_TERM
+        if (ks == KS - 1) {
+          // store the finished tiles (rows 128 pi + 32 (NT pair + e) ..): quad-transposed 16-byte stores, see
+          // gemm_nn_res_kernel
+          const int pair = j / KS;
+#pragma unroll
+          for (int e = 0; e < NT; ++e) {
+            const int mrow = pi * BP + (NT * pair + e) * 32;
+#pragma unroll
+            for (int G = 0; G < 4; ++G) {
+              float a0 = acc[e][4 * G], a1 = acc[e][4 * G + 1], a2 = acc[e][4 * G + 2], a3 = acc[e][4 * G + 3];
+              res_transpose4(a0, a1, a2, a3);
+              f32x4 v = {a0, a1, a2, a3};
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, vy + (mrow + 8 * G) * ldy * 4, 0, 0);
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = (NIT - PD > 0 ? NIT - PD : 0); q < NLD; ++q) panel_store(buf ^ 1, q, stage[q]);   // write slots behind the last iteration
+      __syncthreads();   // the next panel is complete in the other buffer; everyone is done reading this one
+    }
+  }
+}
+
+int g_res_tm = 0, g_res_wgs = 0;   // development overrides (knobs 21, 23): 0 = automatic
+int g_bst_mode = -1;   // knob 24 (B-stationary kernel): -1 automatic, 0 never, 1 whenever the shape is served
 int g_res_mode = -1;   // knob 20: -1 automatic, 0 never, 1 whenever the shape is served
 
 template <int TM, int KS, int NW, bool A_PRE>
@@ -311,9 +505,8 @@ int pir_nn_res_tune(int knob, int value) {
   return PIR_EINVAL;
 }
 
-int g_res_tm = 0, g_res_wgs = 0;   // development overrides (knobs 21, 23): 0 = automatic
 int pir_nn_res_tune2(int knob, int value) {
-  if (knob == 21) g_res_tm = value; else if (knob == 23) g_res_wgs = value; else return PIR_EINVAL;
+  if (knob == 21) g_res_tm = value; else if (knob == 23) g_res_wgs = value; else if (knob == 24) g_bst_mode = value; else return PIR_EINVAL;
   return PIR_OK;
 }
 
@@ -376,17 +569,70 @@ static bool res_plan(const pir_gemm_nn_t& g, ResPlan& pl) {
   }
   // every wave should get a few blocks, or the one-off panel load is not amortised: automatic mode only takes long streams
   if (g_res_mode < 0 && pl.per_slice < 2 * pl.nw) return false;
+  // ... and only the shape class where the A/B shows a gain over the tiled kernel (tools/resident_ab.py): three row
+  // blocks of 96 rows against K = 96 on full-resolution planes (qkv forward of the 96-channel 128^2 levels, M = 288)
+  if (g_res_mode < 0 && !(pl.pre && pl.ks == 6 && g.M > 256 && g.M <= 384 && g.N >= 16384 && g.R == nullptr)) return false;
   pl.grid = (int)(slices * pl.row_tiles);
   return true;
 }
 
-bool pir_nn_res_wanted(const pir_gemm_nn_t* a) {
+static bool bst_plan(const pir_gemm_nn_t& g, BstArgs& a, int& grid) {
+  if (g_bst_mode == 0) return false;
+  if (g.O2 != 1 || g.N % 32 != 0 || g.N < 32 || g.rowscale != nullptr || g.R != nullptr) return false;
+  if (g.A3 == nullptr || g.a_s1 != 0 || g.a_s2 != 0) return false;
+  const int kp = (int)(pir_cdiv(g.K, 16) * 16);
+  if (g.a3_kp != kp || (kp != 48 && kp != 96)) return false;
+  // automatic use where the A/B over the step's shapes shows a gain (tools/resident_ab.py, profiles/r03_resident_ab.txt):
+  // project_in forward (M = 254 / 510) at the 128^2 and 64^2 levels, project_out input gradient (M = 255) at 64^2
+  if (g_bst_mode < 0 && !(g.M >= 384 || (g.M >= 250 && g.M <= 256 && (kp == 48 || g.N <= 4096)))) return false;
+  if (g_bst_mode < 0 && g.N < 4096) return false;
+  if ((reinterpret_cast<uintptr_t>(g.Y) & 15) || g.ldy % 4 || g.y_s1 % 4) return false;
+  if (g.R && ((reinterpret_cast<uintptr_t>(g.R) & 15) || g.ldr % 4 || g.r_s1 % 4)) return false;
+  if ((reinterpret_cast<uintptr_t>(g.X) & 15) || g.ldx % 4 || g.x_s1 % 4) return false;
+  if ((long)(g.M + 128) * g.ldy * 4 >= (1L << 31) || (g.R && (long)(g.M + 128) * g.ldr * 4 >= (1L << 31))) return false;
+  if ((kp * g.ldx + g.N) * 4 >= (1L << 31) || 6L * g.M * kp >= (1L << 31)) return false;
+  a.g = g;
+  a.nbpi = g.N / 32;
+  a.magic_nbpi = pir_magic((unsigned)a.nbpi);
+  a.blocks_total = g.O1 * a.nbpi;
+  if ((long)a.blocks_total * (a.nbpi > 1 ? a.nbpi : 2) >= (1L << 32)) return false;
+  // panel height 96 or 128 rows, whichever pads M less (K = 48 keeps 128: its two-tile groups need an even count)
+  const int bp = (kp == 96 && pir_cdiv(g.M, 96) * 96 < pir_cdiv(g.M, 128) * 128) ? 96 : 128;
+  a.panels = (int)pir_cdiv(g.M, bp);
+  long wgs = g_res_wgs ? g_res_wgs : PIR_NUM_CU;            // one eight-wave workgroup per CU
+  long per = pir_cdiv(pir_cdiv(a.blocks_total, wgs), 8) * 8;
+  if (g_bst_mode < 0 && per < 16) return false;             // at least two rounds per workgroup
+  a.per_wg = (int)per;
+  grid = (int)pir_cdiv(a.blocks_total, per);
+  return true;
+}
+
+int pir_nn_bst_launch(const pir_gemm_nn_t* g, hipStream_t s) {
+  BstArgs a;
+  int grid = 0;
+  if (!bst_plan(*g, a, grid)) return 1000;
+  const bool p96 = (long)a.panels * 96 >= g->M && (long)a.panels * 96 < pir_cdiv(g->M, 128) * 128 && g->a3_kp == 96;
+  if (g->a3_kp == 96 && p96) hipLaunchKernelGGL((gemm_nn_bst_kernel<6, 1, 3>), dim3((unsigned)grid), dim3(512), 0, s, a);
+  else if (g->a3_kp == 96) hipLaunchKernelGGL((gemm_nn_bst_kernel<6, 1, 4>), dim3((unsigned)grid), dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((gemm_nn_bst_kernel<3, 2, 4>), dim3((unsigned)grid), dim3(512), 0, s, a);
+  return pir_launch_status();
+}
+
+// 0: not served, 1: resident-panel kernel, 2: B-stationary kernel
+int pir_nn_res_kind(const pir_gemm_nn_t* a) {
+  BstArgs b;
+  int grid;
+  if (bst_plan(*a, b, grid)) return 2;
   ResPlan pl;
-  return res_plan(*a, pl);
+  return res_plan(*a, pl) ? 1 : 0;
 }
 
 int pir_nn_res_launch(const pir_gemm_nn_t* a, hipStream_t s) {
   const pir_gemm_nn_t& g = *a;
+  {
+    const int st = pir_nn_bst_launch(a, s);
+    if (st != 1000) return st;
+  }
   ResPlan pl;
   if (!res_plan(g, pl)) return 1000;
   ResArgs ra;

@@ -208,14 +208,19 @@ def test_gemm_plan_reaches_the_tuned_tiles_for_config3_shapes():
         g = _lib.GemmNN()
         g.M, g.K, g.N, g.O1, g.O2, g.ldx, g.ldy = M, K, N, batch, 1, N, N
         g.A3 = 256 if presplit else None
+        g.a3_kp = (K + 15) // 16 * 16 if presplit else 0
         return _lib.lib.pir_gemm_nn_plan(ctypes.byref(g))
 
-    assert plan(510, 96, 16384, 32) == 2222      # project_in forward, dec1 / refinement: 128 x 128 (M pads to 512)
-    assert plan(96, 510, 16384, 32) == 3114      # its input gradient (M = 96, K = 510, N = 16384): 96 x 128
-    assert plan(510, 96, 4096, 32) == 2222       # level 2 forward
-    assert plan(255, 96, 16384, 32) == 2222      # project_out input gradient
+    # round 3: long pixel streams against short k run on the persistent kernels of gemm_res.hip
+    assert plan(510, 96, 16384, 32) == 9100      # project_in forward, dec1 / refinement: B-stationary (activations split once)
+    assert plan(510, 96, 4096, 32) == 9100       # level 2 forward
+    assert plan(254, 48, 16384, 32) == 9100      # level 1 encoder
+    assert plan(255, 96, 4096, 32) == 9100       # project_out input gradient, level 2
+    assert plan(288, 96, 16384, 32) == 9000      # qkv forward, dec1 / refinement: resident weight panel, three row tiles
+    assert plan(510, 96, 16384, 2) == 2222       # a test-sized batch has too few column blocks per workgroup: 128 x 128 tiles
+    assert plan(96, 510, 16384, 32) == 3114      # project_in input gradient (M = 96, K = 510, N = 16384): 96 x 128
+    assert plan(255, 96, 16384, 32) == 2222      # project_out input gradient at 128^2 (A/B: no gain from the persistent kernels)
     assert plan(96, 510, 16384, 2) == 3114       # the test-sized batch takes the same branch
-    assert plan(288, 96, 16384, 32) == 3214      # qkv: 96 x 256
     assert plan(48, 48, 16384, 32) == 1222
     assert plan(48, 144, 16384, 32) == 1222      # 64 x 128 up to k = 192 ...
     assert plan(48, 254, 16384, 32) == 2214      # ... 64 x 256 beyond

@@ -14,9 +14,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("cout", type=int); ap.add_argument("cin", type=int); ap.add_argument("side", type=int)
 ap.add_argument("--res", type=int, default=-1); ap.add_argument("--dgrad", action="store_true")
 ap.add_argument("--batch", type=int, default=32); ap.add_argument("--iters", type=int, default=20)
-ap.add_argument("--tm", type=int, default=0); ap.add_argument("--wgs", type=int, default=0)
+ap.add_argument("--tm", type=int, default=0); ap.add_argument("--wgs", type=int, default=0); ap.add_argument("--bst", type=int, default=-1)
 a = ap.parse_args()
-_lib.lib.pir_tune_set(20, a.res); _lib.lib.pir_tune_set(21, a.tm); _lib.lib.pir_tune_set(23, a.wgs)
+_lib.lib.pir_tune_set(20, a.res); _lib.lib.pir_tune_set(21, a.tm); _lib.lib.pir_tune_set(23, a.wgs); _lib.lib.pir_tune_set(24, a.bst)
 dev = "cuda:0"
 w = torch.randn(a.cout, a.cin, 1, 1, device=dev)
 if a.dgrad:

@@ -1,7 +1,7 @@
 set -u
 SHAPE=${SHAPE:-"510 96 128"}
 ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out/r03_pmc_res; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-for mode in 0 1; do
+for mode in ${MODES:-0 1}; do
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/sq_$mode -- python3 $ROOT/tools/one_gemm.py $SHAPE --res $mode --iters 6 > $OUT/sq_$mode.log 2>&1
   rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE GRBM_TA_BUSY --output-format csv -d $OUT/grbm_$mode -- python3 $ROOT/tools/one_gemm.py $SHAPE --res $mode --iters 6 > $OUT/grbm_$mode.log 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$mode -- python3 $ROOT/tools/one_gemm.py $SHAPE --res $mode --iters 6 > $OUT/fetch_$mode.log 2>&1
