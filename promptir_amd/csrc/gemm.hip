@@ -503,7 +503,7 @@ constexpr int X3_BK = 16;
 // stores its 4 pixels (8 bytes per piece), instead of two lanes x two 16-byte loads per row: one L1 request per row and
 // stage instead of two.
 template <int TM, int TN, int WM, int WN, bool TAPS = false, bool QUAD = false>
-__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(3)))
+__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WM * WN >= 8 ? 4 : 3)))
 void gemm_nt_x3_kernel(NTParams p) {
   static_assert(!(TAPS && QUAD), "the tap-shifted operand keeps the fragment mapping");
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, T = WM * WN * 64;
@@ -826,15 +826,18 @@ struct NTPlan {
   int splits, chunks_per_r;
 };
 
-NTPlan nt_plan(int M1, int M2, int N, int O, int BR, int bk = NT_BK) {
+NTPlan nt_plan(int M1, int M2, int N, int O, int BR, int bk = NT_BK, bool wide_ok = false) {
   NTPlan pl;
   if (g_nt_cfg >= 0) {
     pl.cfg = g_nt_cfg;
-    pl.bm = g_nt_cfg == 0 ? 64 : 128;
-    pl.bn = g_nt_cfg == 0 || g_nt_cfg == 1 ? 64 : (g_nt_cfg == 2 ? 96 : 128);
+    const int c = (g_nt_cfg >= 4 && !(wide_ok && bk == X3_BK)) ? 3 : g_nt_cfg;   // the eight-wave tiles exist for the plain bf16x3 kernel only
+    pl.cfg = c;
+    pl.bm = c == 0 ? 64 : (c >= 4 ? 256 : 128);
+    pl.bn = c == 0 || c == 1 ? 64 : (c == 2 || c == 4 ? 96 : 128);
   } else if (M1 <= 64 && M2 <= 64) { pl.cfg = 0; pl.bm = 64; pl.bn = 64; }
   else if (M2 <= 64) { pl.cfg = 1; pl.bm = 128; pl.bn = 64; }
   else {
+    // (eight-wave 256 x 96 / 256 x 128 tiles exist behind knob 1 = 4 / 5: measured slower at every level, round 3)
     const long pad96 = pir_cdiv(M2, 96) * 96, pad128 = pir_cdiv(M2, 128) * 128;
     if (pad96 < pad128) { pl.cfg = 2; pl.bm = 128; pl.bn = 96; } else { pl.cfg = 3; pl.bm = 128; pl.bn = 128; }
   }
@@ -871,7 +874,7 @@ int launch_nt(NTParams& p, size_t ws_floats, int tap_sign, long g_st, hipStream_
   const bool x3 = vec4 && (g_nt_x3 != 0 || tap_sign != 0);   // bf16x3 matrix-core path whenever rows are 16-byte aligned
   if (tap_sign != 0 && !x3) return PIR_EINVAL;
   if ((long)g.BR * pir_cdiv(g.N, x3 ? X3_BK : NT_BK) >= 2147483647L) return PIR_EINVAL;   // 32-bit stage counters
-  NTPlan pl = nt_plan(g.M1, g.M2, g.N, O, g.BR, x3 ? X3_BK : NT_BK);
+  NTPlan pl = nt_plan(g.M1, g.M2, g.N, O, g.BR, x3 ? X3_BK : NT_BK, x3 && tap_sign == 0);
   if ((size_t)pl.splits * O * g.M1 * g.M2 > ws_floats) return PIR_ENOMEM;
   p.splits = pl.splits;
   p.chunks_per_r = pl.chunks_per_r;
@@ -890,6 +893,8 @@ int launch_nt(NTParams& p, size_t ws_floats, int tap_sign, long g_st, hipStream_
       case 0: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 1, 2, 2, false, true>), grid, dim3(256), 0, s, p); break;
       case 1: hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 1, 2, 2, false, true>), grid, dim3(256), 0, s, p); break;
       case 2: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 3, 4, 1, false, true>), grid, dim3(256), 0, s, p); break;
+      case 4: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 3, 8, 1, false, true>), grid, dim3(512), 0, s, p); break;   // 256 x 96
+      case 5: hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2, 4, 2, false, true>), grid, dim3(512), 0, s, p); break;   // 256 x 128
       default: hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2, 2, 2, false, true>), grid, dim3(256), 0, s, p); break;
     }
   } else if (x3) {
@@ -897,6 +902,8 @@ int launch_nt(NTParams& p, size_t ws_floats, int tap_sign, long g_st, hipStream_
       case 0: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 1, 2, 2>), grid, dim3(256), 0, s, p); break;   // 64 x 64
       case 1: hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 1, 2, 2>), grid, dim3(256), 0, s, p); break;   // 128 x 64
       case 2: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 3, 4, 1>), grid, dim3(256), 0, s, p); break;   // 128 x 96
+      case 4: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 3, 8, 1>), grid, dim3(512), 0, s, p); break;   // 256 x 96
+      case 5: hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2, 4, 2>), grid, dim3(512), 0, s, p); break;   // 256 x 128
       default: hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p); break;  // 128 x 128
     }
   } else {
@@ -1000,9 +1007,12 @@ extern "C" size_t pir_gemm_nt_ws_floats(int M1, int M2, int N, int O, int BR) {
   // the launcher may swap the operands so that the larger extent plays M1: size for the worst of both
   NTPlan a = nt_plan(M1, M2, N, O, BR), b = nt_plan(M2, M1, N, O, BR);
   NTPlan c = nt_plan(M1, M2, N, O, BR, X3_BK), d = nt_plan(M2, M1, N, O, BR, X3_BK);
+  NTPlan e = nt_plan(M1, M2, N, O, BR, X3_BK, true), f = nt_plan(M2, M1, N, O, BR, X3_BK, true);
   int s = a.splits > b.splits ? a.splits : b.splits;
   if (c.splits > s) s = c.splits;
   if (d.splits > s) s = d.splits;
+  if (e.splits > s) s = e.splits;
+  if (f.splits > s) s = f.splits;
   if (g_nt_splits > s) s = g_nt_splits;
   return (size_t)s * O * M1 * M2;
 }
