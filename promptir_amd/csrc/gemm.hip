@@ -875,13 +875,23 @@ int launch_nt(NTParams& p, size_t ws_floats, int tap_sign, long g_st, hipStream_
   if (tap_sign != 0 && !x3) return PIR_EINVAL;
   if ((long)g.BR * pir_cdiv(g.N, x3 ? X3_BK : NT_BK) >= 2147483647L) return PIR_EINVAL;   // 32-bit stage counters
   NTPlan pl = nt_plan(g.M1, g.M2, g.N, O, g.BR, x3 ? X3_BK : NT_BK, x3 && tap_sign == 0);
+  int xp_splits = 0;
+  if (x3 && tap_sign == 0 && g_nt_cfg < 0 && g_nt_splits == 0) {
+    // tall x small weight gradients: the tall operand stays private to its wave, only the small one goes through LDS
+    const int st = pir_nt_xp_launch(&g, &xp_splits, s);
+    if (st != 1000 && st != PIR_OK) return st;
+    if (st == 1000) xp_splits = 0;
+  }
+  if (xp_splits > 0) pl.splits = xp_splits;
   if ((size_t)pl.splits * O * g.M1 * g.M2 > ws_floats) return PIR_ENOMEM;
   p.splits = pl.splits;
   p.chunks_per_r = pl.chunks_per_r;
   p.tap_sign = tap_sign;
   p.magic_w = pir_magic(g.W > 0 ? (unsigned)g.W : 1u);
   dim3 grid((unsigned)(pir_cdiv(g.M1, pl.bm) * pir_cdiv(g.M2, pl.bn)), (unsigned)pl.splits, (unsigned)O);
-  if (tap_sign != 0) {
+  if (xp_splits > 0) {
+    // partials already written by gemm_nt_xp_kernel
+  } else if (tap_sign != 0) {
     switch (pl.cfg) {
       case 0: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 1, 2, 2, true>), grid, dim3(256), 0, s, p); break;
       case 1: hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 1, 2, 2, true>), grid, dim3(256), 0, s, p); break;
@@ -948,6 +958,7 @@ extern "C" int pir_tune_set(int knob, int value) {
     case 19: g_nt_want_half = value; return PIR_OK;
     case 20: return pir_nn_res_tune(knob, value);
     case 21: case 22: case 23: case 24: return pir_nn_res_tune2(knob, value);
+    case 25: return pir_nt_xp_tune(knob, value);
     default: return PIR_EINVAL;
   }
 }
@@ -1014,6 +1025,7 @@ extern "C" size_t pir_gemm_nt_ws_floats(int M1, int M2, int N, int O, int BR) {
   if (e.splits > s) s = e.splits;
   if (f.splits > s) s = f.splits;
   if (g_nt_splits > s) s = g_nt_splits;
+  if (O == 1 && s < 2 * PIR_NUM_CU) s = 2 * PIR_NUM_CU;   // gemm_nt_xp_kernel: up to two slices per CU
   return (size_t)s * O * M1 * M2;
 }
 

@@ -94,6 +94,9 @@ if _os.environ.get("PIR_NN_X3") is not None:
     _lib.lib.pir_tune_set(3, int(_os.environ["PIR_NN_X3"]))
 if _os.environ.get("PIR_NT_X3") is not None:
     _lib.lib.pir_tune_set(4, int(_os.environ["PIR_NT_X3"]))
+for _kv in filter(None, _os.environ.get("PIR_KNOBS", "").split(",")):   # "20=0,25=0": any pir_tune_set knob (tools A/B)
+    _k, _v = _kv.split("=")
+    check(_lib.lib.pir_tune_set(int(_k), int(_v)), "pir_tune_set(%s)" % _kv)
 
 
 # ----------------------------------------------------------------------------- plumbing

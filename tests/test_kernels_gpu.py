@@ -102,6 +102,34 @@ def test_persistent_gemm_kernels(b, cin, cout, h, w, res):
     assert torch.equal(outs["tiled"], outs["resident"]) and torch.equal(outs["tiled"], outs["bstationary"])
 
 
+@pytest.mark.parametrize("b,cin,cout,h,w", [(2, 96, 510, 16, 16), (3, 48, 254, 8, 16), (2, 96, 288, 16, 8), (2, 90, 300, 8, 8),
+                                            (2, 40, 130, 8, 8), (3, 255, 96, 16, 8), (1, 96, 510, 128, 128), (5, 127, 48, 8, 8),
+                                            (2, 96, 479, 8, 12)])
+def test_weight_gradient_with_the_tall_operand_private_to_its_wave(b, cin, cout, h, w):
+    """gemm_ntx.hip forced on (knob 25 = 1): ragged row counts on both operands (M1 = 130 .. 510 incl. waves whose
+    second row block lies beyond M1, M2 = 40 .. 96), operands swapped by the launcher (255 x 96), several images per
+    slice, vs autograd of F.conv2d on the CPU and vs the tiled kernel (other summation order: tolerance), and
+    bit-stable across repeated launches (deterministic two-stage reduction)."""
+    from promptir_amd import _lib, ops
+
+    L = _lib.lib
+    x, dy = rnd("x", b, cin, h, w), rnd("dy", b, cout, h, w)
+    wr = rnd("w", cout, cin, 1, 1).requires_grad_(True)
+    F.conv2d(x, wr).backward(dy)
+    xd, dyd, like = x.to(DEV), dy.to(DEV), wr.detach().to(DEV)
+    try:
+        assert L.pir_tune_set(25, 0) == 0
+        tiled = ops.conv1x1_wgrad(dyd, xd, like).clone()
+        assert L.pir_tune_set(25, 1) == 0
+        got = ops.conv1x1_wgrad(dyd, xd, like).clone()
+        again = ops.conv1x1_wgrad(dyd, xd, like).clone()
+    finally:
+        L.pir_tune_set(25, -1)
+    close(got, wr.grad, rtol=5e-5)
+    close(got, tiled.cpu(), rtol=2e-5)
+    assert torch.equal(got, again)
+
+
 def test_persistent_gemm_kernels_are_selected_for_the_config3_shapes():
     """The automatic plan takes the persistent kernels for the batch-32 shapes the A/B showed a gain on, and those
     launches agree with the tiled kernel bit for bit at full size (batch 32 x 128 x 128: eight rounds per workgroup)."""
