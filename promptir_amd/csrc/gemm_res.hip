@@ -151,7 +151,7 @@ void gemm_nn_res_kernel(ResArgs p) {
   // quad) with lane bits 3, 2 (row): the lane holds rows 4t .. 4t + 3 of ONE pixel, the MFMA B-operand layout, with
   // lane l standing for column 4m + (l3 l2) of the block - a fixed permutation of the 32 columns that the accumulators
   // inherit and the store tail undoes the same way.  The row term sits in the per-lane offset, so rows beyond K (and
-  // everything past the image) are zeroed by the range check (scalar offsets are NOT range-checked).
+  // everything past the image) are zeroed by the range check.
   const int qk = ((r >> 4) << 2) | (r & 3), qj = (r >> 2) & 3;
   f32x4 raw[PF][2];
   struct Cols { __amdgpu_buffer_rsrc_t rs; int vo; };

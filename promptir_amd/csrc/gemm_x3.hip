@@ -71,7 +71,9 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
   auto a_map = [&](int f, int& mm, int& kg) { if (A_MFAST) { mm = f % BM; kg = f / BM; } else { kg = f & 1; mm = f >> 1; } };
 
   // Buffer descriptors (wave-uniform): B rows beyond K and everything past the last valid element read as 0
-  // through the hardware range check, so the k tail needs no masks; per-lane offsets are computed once and
+  // through the hardware range check, so the k tail needs no masks (the check covers the scalar row offset too on
+  // gfx950: tests/test_kernels_gpu.py::test_k_tail_never_multiplies_what_lies_behind_the_operand puts NaNs behind the
+  // operand); per-lane offsets are computed once and
   // each load adds a scalar row offset (no vector address arithmetic inside the k loop).
   const __amdgpu_buffer_rsrc_t xrs = pir_make_rsrc(X, (unsigned)((((long)g.K - 1) * g.ldx + g.N) * 4));
   const __amdgpu_buffer_rsrc_t ars = pir_make_rsrc(g.A3, A_PRE ? (unsigned)((CONV ? 54L : 6L) * g.M * g.a3_kp) : 0u);

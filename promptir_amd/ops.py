@@ -225,13 +225,19 @@ def _refresh_split_batch() -> None:
     """Re-split every registered weight with ONE launch (pir_split_bf16x3_batch) and mark all entries current."""
     import numpy as np
 
-    ents = [e for e in _BATCH["entries"] if e["w"]() is not None]
-    ptrs = [(e["w"]().data_ptr(), e["buf"].data_ptr()) for e in ents]
+    # strong references for the duration of the call: building the lists below allocates, an allocation can run the
+    # garbage collector, and a collected module's weights would turn their weak references to None under our feet
+    live = [(e, e["w"]()) for e in _BATCH["entries"]]
+    live = [(e, w) for e, w in live if w is not None]
+    ents = [e for e, _ in live]
+    ptrs = [(w.data_ptr(), e["buf"].data_ptr()) for e, w in live]
     if _BATCH["dirty"] or ptrs != _BATCH["ptrs"] or len(ents) != len(_BATCH["entries"]):
+        if not live:
+            _BATCH["entries"], _BATCH["ptrs"], _BATCH["nblocks"], _BATCH["dirty"] = [], [], 0, False
+            return
         descs = (_lib.SplitDesc * len(ents))()
         blocks = []
-        for i, e in enumerate(ents):
-            w = e["w"]()
+        for i, (e, w) in enumerate(live):
             M, K, sm, sk = _split_args(w, e["dgrad"], e["taps"])
             d = descs[i]
             d.W, d.out, d.st, d.sm, d.sk = w.data_ptr(), e["buf"].data_ptr(), 1, sm, sk
@@ -243,11 +249,12 @@ def _refresh_split_batch() -> None:
         _BATCH["descs"] = torch.from_numpy(raw).to(dev)
         _BATCH["blocks"] = torch.tensor(blocks, dtype=torch.int32, device=dev).contiguous()
         _BATCH["nblocks"], _BATCH["ptrs"], _BATCH["entries"], _BATCH["dirty"] = len(blocks), ptrs, ents, False
+    if not live:
+        return
     check(lib.pir_split_bf16x3_batch(_BATCH["descs"].data_ptr(), _BATCH["blocks"].data_ptr(), _BATCH["nblocks"], _stream()),
           "pir_split_bf16x3_batch")
     gen = _WEIGHT_GEN[0]
-    for e in ents:
-        w = e["w"]()
+    for e, w in live:
         e["slot"][e["skey"]] = ((w.data_ptr(), w._version, gen), e["buf"])
 
 

@@ -130,6 +130,38 @@ def test_weight_gradient_with_the_tall_operand_private_to_its_wave(b, cin, cout,
     assert torch.equal(got, again)
 
 
+@pytest.mark.parametrize("b,cin,cout,h,w", [(2, 510, 192, 32, 32), (1, 127, 48, 16, 16), (2, 255, 96, 64, 64), (1, 1021, 384, 16, 16),
+                                            (2, 90, 300, 8, 16), (1, 3, 48, 16, 16)])
+def test_k_tail_never_multiplies_what_lies_behind_the_operand(b, cin, cout, h, w):
+    """K is no multiple of the 16-deep matrix-core step: the rows K .. 15 of the last step must not be READ (the weight
+    columns there are zero, but 0 x NaN is NaN).  The activations are the tail of a larger buffer whose remainder is NaN.
+    The tiled kernel relies on the buffer descriptor's range check INCLUDING the scalar row offset (true on gfx950; LLVM
+    documents the scalar offset as unchecked), the persistent kernels keep the row in the per-lane offset: this test pins
+    both (tiled kernel with and without its register-resident activations, the persistent kernels, the dense 3x3 kernel)."""
+    from promptir_amd import _lib, ops
+
+    L = _lib.lib
+    x, wt = rnd("x", b, cin, h, w), rnd("w", cout, cin, 1, 1)
+    n = x.numel()
+    buf = torch.full((n + 64 * h * w,), float("nan"), device=DEV)
+    buf[:n] = x.reshape(-1).to(DEV)
+    xd = buf[:n].view(b, cin, h, w)
+    ref = F.conv2d(x, wt)
+    try:
+        for k20, k24 in ((0, 0), (1, 0), (1, 1)):
+            L.pir_tune_set(20, k20); L.pir_tune_set(24, k24)
+            y = ops.conv1x1_forward(xd, wt.to(DEV))
+            assert bool(torch.isfinite(y).all()), (k20, k24)
+            close(y, ref)
+    finally:
+        L.pir_tune_set(20, -1); L.pir_tune_set(24, -1)
+    if cin <= 127:
+        w3 = rnd("w3", cout, cin, 3, 3)
+        y3 = ops.conv3x3_forward(xd, w3.to(DEV))
+        assert bool(torch.isfinite(y3).all())
+        close(y3, F.conv2d(x, w3, padding=1))
+
+
 def test_persistent_gemm_kernels_are_selected_for_the_config3_shapes():
     """The automatic plan takes the persistent kernels for the batch-32 shapes the A/B showed a gain on, and those
     launches agree with the tiled kernel bit for bit at full size (batch 32 x 128 x 128: eight rounds per workgroup)."""

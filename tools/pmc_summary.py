@@ -99,11 +99,11 @@ def is_conv(k):
 fam = {}
 for r in rows:
     k = r["kernel"]
-    if k.startswith("gemm_nn_x3_kernel") and not is_conv(k):
+    if (k.startswith("gemm_nn_x3_kernel") and not is_conv(k)) or k.startswith("gemm_nn_res_kernel") or k.startswith("gemm_nn_bst_kernel"):
         name = "pir_gemm_nn"
     elif k.startswith("gemm_nn_x3_kernel"):
         name = "pir_conv3x3_x3"
-    elif k.startswith("gemm_nt_x3_kernel") or k.startswith("nt_reduce"):
+    elif k.startswith("gemm_nt_x3_kernel") or k.startswith("gemm_nt_xp_kernel") or k.startswith("nt_reduce"):
         name = "pir_gemm_nt"
     else:
         name = k.split("<")[0]
