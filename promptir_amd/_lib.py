@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PIR_LIB", os.path.join(_HERE, "libpromptir_hip.so"))  # PIR_LIB: A/B builds in tools/
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_float_p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 c_long = C.c_long
