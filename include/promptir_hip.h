@@ -231,6 +231,16 @@ int pir_mdta_softmax_bwd(const float* dattn, const float* attn, const float* gra
                          float* alpha_q, float* alpha_k, float* dtemp_partial,
                          int B, int heads, int c, pir_stream_t stream);
 
+/* dq and dk of the MDTA backward from ONE pass over q and k (round 3):
+ *   dq[b,h] = dgram[b,h] k[b,h] + alpha_q * q[b,h],   dk[b,h] = dgram[b,h]^T q[b,h] + alpha_k * k[b,h]
+ * q of (b, h) starts at q + b*q_bs + h*c*HW (rows at stride HW), k at + k_off; dq / dk likewise at dq + b*dq_bs + h*c*HW
+ * (+ dk_off).  Replaces the two pir_gemm_nn calls (each of which reads q AND k) of net/model.py:127-131's backward.
+ * Served for c == 48 and HW % 32 == 0 with 16-byte aligned planes; returns 1000 (nothing launched) otherwise and the
+ * caller keeps the two-GEMM path. */
+int pir_mdta_dqk(const float* dgram, const float* q, long q_bs, long k_off, const float* alpha_q,
+                 const float* alpha_k, float* dq, long dq_bs, long dk_off, int B, int heads, int c, int HW,
+                 pir_stream_t stream);
+
 /* ------------------------------------------------------------------ pixel (un)shuffle
  * nn.PixelUnshuffle(2) / nn.PixelShuffle(2) (net/model.py:165,175). Each is the other's adjoint.
  * unshuffle: y[b][c*4+i*2+j][h][w] = x[b][c][2h+i][2w+j]   (x is [B][C][2H][2W], y [B][4C][H][W])

@@ -19,6 +19,7 @@
 //     fp32 fragments in registers), so a wave never sees a cold prologue again after its first block.
 // Per (m, n) the k order and the order of the six bf16 terms are those of gemm_nn_x3_kernel: results are bit-identical.
 #include "gemm_common.h"
+#include "wide_tiles.h"
 
 namespace {
 
@@ -38,26 +39,6 @@ __device__ __forceinline__ Frag3 res_split8(const float (&v)[8]) {
     f.hi[j] = h; f.mid[j] = m; f.lo[j] = (__bf16)r2;
   }
   return f;
-}
-
-// Exchange of a register-index bit with a lane-index bit (the 2 x 2 block transpose that a 4 x 4 transpose is made of)
-// for lane bits 2 and 3: a DPP row shift by 4 (8) lanes whose bank mask writes only the lanes with that bit set
-// (cleared) IS the conditional move - one VALU operation per register, no select.  Banks are the four lane quads of a
-// 16-lane row: lane bit 2 set = banks 1, 3 (0xA), clear = 0x5; lane bit 3 set = banks 2, 3 (0xC), clear = 0x3.
-template <int BIT>
-__device__ __forceinline__ void res_exchange(float& lo, float& hi) {
-  constexpr int SH = BIT == 2 ? 4 : 8, SET = BIT == 2 ? 0xA : 0xC, CLR = BIT == 2 ? 0x5 : 0x3;
-  const int l = __builtin_bit_cast(int, lo), h = __builtin_bit_cast(int, hi);
-  // lanes with the bit set: lo <- hi of the lane SH below;  lanes with it clear: hi <- lo of the lane SH above
-  const int nl = __builtin_amdgcn_update_dpp(l, h, 0x110 + SH, 0xf, SET, false);
-  const int nh = __builtin_amdgcn_update_dpp(h, l, 0x100 + SH, 0xf, CLR, false);
-  lo = __builtin_bit_cast(float, nl); hi = __builtin_bit_cast(float, nh);
-}
-// v[e] (e = 2 e1 + e0) at lane bits (l3, l2) = (a1, a0)  ->  v[2 a1 + a0] at lane bits (e1, e0): the 4 x 4 transpose
-// between four registers and the lane-index bits 3, 2 in eight VALU operations.
-__device__ __forceinline__ void res_transpose4(float& v0, float& v1, float& v2, float& v3) {
-  res_exchange<2>(v0, v1); res_exchange<2>(v2, v3);
-  res_exchange<3>(v0, v2); res_exchange<3>(v1, v3);
 }
 
 struct ResArgs {

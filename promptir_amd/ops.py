@@ -569,6 +569,16 @@ def mdta_attn_backward(dattn, qkv, temperature, heads, attn, gram, sumsq, dqkv, 
     check(lib.pir_mdta_softmax_bwd(dattn.data_ptr(), attn.data_ptr(), gram.data_ptr(), sumsq.data_ptr(), sumsq.shape[1],
                                    temperature.data_ptr(), dgram.data_ptr(), alpha_q.data_ptr(), alpha_k.data_ptr(),
                                    dtemp_part.data_ptr(), b, heads, c, _stream()), "pir_mdta_softmax_bwd")
+    # dq = dG k + alpha_q * q and dk = dG^T q + alpha_k * k from ONE pass over q and k where the fused kernel serves the
+    # shape (48 rows per head, whole 32-pixel blocks); 1000 = not served, nothing launched
+    if MDTA_DQK:
+        st = lib.pir_mdta_dqk(dgram.data_ptr(), qkv.data_ptr(), bs, c_all * hw, alpha_q.data_ptr(), alpha_k.data_ptr(),
+                              dqkv.data_ptr(), qbs, c_all * hw, b, heads, c, hw, _stream())
+        if st != 1000:
+            check(st, "pir_mdta_dqk")
+            dtemp = _grad_out(temperature, dtemp_out)
+            reduce_partials(dtemp_part, heads, b, dtemp, heads)
+            return dtemp
     # dq = dG k + alpha_q * q
     gemm_nn(dgram, (heads * c * c, c * c), c, 1, qkv, c_all * hw, (bs, c * hw), hw,
             dqkv, 0, (qbs, c * hw), hw, c, c, hw, b, heads,
@@ -860,6 +870,7 @@ class MdtaCoreFn(torch.autograd.Function):
 
 USE_SIDE_STREAM = _os.environ.get("PIR_SIDE_STREAM", "1") != "0"   # default for callers outside a trainer
 MDTA_FOLD = _os.environ.get("PIR_MDTA_FOLD", "1") != "0"             # fold attn @ v into project_out (TransformerBlockFn)
+MDTA_DQK = _os.environ.get("PIR_MDTA_DQK", "1") != "0"               # dq and dk from one pass over q and k (mdta_dqk.hip)
 MDTA_FOLD_MIN_HW = int(_os.environ.get("PIR_MDTA_FOLD_MIN_HW", "4096"))   # ... at the 64^2 / 128^2 levels (below, the
 # C x C x c products it adds cost as much as the launch-bound GEMMs it removes: bench A/B, round 2)
 _SIDE_STREAMS = {}
