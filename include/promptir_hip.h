@@ -73,6 +73,14 @@ typedef struct {
   const void* A3; int a3_kp;
 } pir_gemm_nn_t;
 int pir_gemm_nn(const pir_gemm_nn_t* args, pir_stream_t stream);
+/* y[b] = W LayerNorm_c(x[b]) for the no_grad forward (round 3): the channel LayerNorm (WithBias, net/model.py:60-63) is
+ * applied as the activations are loaded by the persistent B-stationary kernel, so the normalised tensor of
+ * `self.attn(self.norm1(x))` / `self.ffn(self.norm2(x))` (:192-196) is never written or read.  A3 = pir_split_bf16x3 of
+ * W [M][K].  Served for K = 48 or 96 channels, HW % 32 == 0, 16-byte aligned planes and enough pixels to fill the
+ * chip; returns 1000 (nothing launched) otherwise and the caller runs pir_layernorm_fwd + pir_gemm_nn. */
+int pir_ln_conv1x1_fwd(const float* x, long x_bs, const float* ln_w, const float* ln_b, const void* A3, int a3_kp,
+                       float* y, long y_bs, int B, int M, int K, int HW, pir_stream_t stream);
+
 /* Host-only query: which kernel instantiation pir_gemm_nn would launch for `args` (pointers are not dereferenced
  * except A3 != NULL).  0 = plain fp32-MFMA kernel; otherwise the bf16x3 tile plan TM*1000 + TN*100 + WM*10 + WN
  * (workgroup of WM x WN waves, each TM x TN 32x32 MFMA tiles: 3114 = 96 x 128, 3214 = 96 x 256, 2222 = 128 x 128,

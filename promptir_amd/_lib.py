@@ -107,6 +107,7 @@ SIGNATURES = {
     "pir_gelu_gate": (I, [P, L, P, L, I, I, I, S]),
     "pir_gelu_gate_bwd": (I, [P, L, P, L, P, L, I, I, I, S]),
     "pir_reduce_partials": (I, [P, L, I, F, I, P, L, S]),
+    "pir_ln_conv1x1_fwd": (I, [P, L, P, P, P, I, P, L, I, I, I, I, S]),
     "pir_mdta_dqk": (I, [P, P, L, L, P, P, P, L, L, I, I, I, I, S]),
     "pir_adamw_step": (I, [P, P, P, P, L, F, F, F, F, F, L, F, S]),
 }

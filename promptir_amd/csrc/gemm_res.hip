@@ -278,17 +278,22 @@ struct BstArgs {
   pir_gemm_nn_t g;
   int nbpi; unsigned magic_nbpi; int blocks_total;
   int per_wg;     // column blocks per workgroup (a multiple of 8: one per wave and round)
-  int panels;     // ceil(M / 128)
+  int panels;     // ceil(M / panel height)
+  const float* ln_w; const float* ln_b;   // LN variant: gamma, beta [K] of the channel LayerNorm applied on load
 };
 
 // NT: 32-row output tiles multiplied at a time (2 where registers allow: K = 48); TP: tiles per weight panel (3 or 4:
 // the panel height 32 TP is chosen for the fewest padded rows, 96 for M = 288)
-template <int KS, int NT, int TP>
+// LN: the activations pass through the channel LayerNorm (WithBias: net/model.py:60-63) ON LOAD - a wave holds all K = 16 KS
+// channels of its 32 pixels (one half of them per lane half), so mean and variance come from its own registers plus one
+// exchange between the lane halves, and the normalised tensor is never written or read (no_grad forward: nothing saves it)
+template <int KS, int NT, int TP, bool LN = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
 void gemm_nn_bst_kernel(BstArgs p) {
   constexpr int NW = 8, T = 512, BP = 32 * TP, KG = 2 * KS, PART = KG * BP, PANEL = 3 * PART;
   constexpr int NLD = (PANEL + T - 1) / T;    // 16-byte units per thread and panel
   __shared__ bf16x8 smem[2 * PANEL];
+  __shared__ f32x4 lnp[LN ? 2 * KS * 4 : 1];  // gamma then beta, K floats each
   const pir_gemm_nn_t& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, r = lane & 31;
@@ -354,24 +359,62 @@ void gemm_nn_bst_kernel(BstArgs p) {
   }
   int my = begin + wid;                       // this wave's column block in the current round
   load_raw(my < end ? my : end - 1);
+  if constexpr (LN) {
+    float* lf = reinterpret_cast<float*>(lnp);
+    if (tid < 16 * KS) { lf[tid] = p.ln_w[tid]; lf[16 * KS + tid] = p.ln_b[tid]; }
+  }
   __syncthreads();
 
   const bf16x8* ap0 = smem + h * BP + r;
   int gp = 0;                                 // panels consumed so far: panel gp sits in buffer gp & 1
   for (int round = 0; round < rounds; ++round, my += NW) {
     const bool active = my < end;
-    // ---- this round's fragments: transpose + split, once
+    // ---- this round's fragments: transpose (+ LayerNorm) + split, once
     Frag3 bf[KS];
+    if constexpr (LN) {
+      float val[KS][8];
+      float s1 = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      float v[8];
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        float a0 = raw[ks][t][0], a1 = raw[ks][t][1], a2 = raw[ks][t][2], a3 = raw[ks][t][3];
-        res_transpose4(a0, a1, a2, a3);
-        v[4 * t] = a0; v[4 * t + 1] = a1; v[4 * t + 2] = a2; v[4 * t + 3] = a3;
+        for (int t = 0; t < 2; ++t) {
+          float a0 = raw[ks][t][0], a1 = raw[ks][t][1], a2 = raw[ks][t][2], a3 = raw[ks][t][3];
+          res_transpose4(a0, a1, a2, a3);
+          val[ks][4 * t] = a0; val[ks][4 * t + 1] = a1; val[ks][4 * t + 2] = a2; val[ks][4 * t + 3] = a3;
+          s1 += (a0 + a1) + (a2 + a3);
+        }
+      s1 += __shfl_xor(s1, 32, 64);                       // the other lane half holds the other 8 KS channels of this pixel
+      const float mu = s1 / (float)(16 * KS);
+      float s2 = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { val[ks][e] -= mu; s2 += val[ks][e] * val[ks][e]; }
+      s2 += __shfl_xor(s2, 32, 64);
+      const float rstd = 1.f / sqrtf(s2 / (float)(16 * KS) + 1e-5f);   // biased variance, eps inside the root (:62-63)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const f32x4 gm = lnp[(16 * ks + 8 * h + 4 * t) >> 2], bt = lnp[4 * KS + ((16 * ks + 8 * h + 4 * t) >> 2)];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[4 * t + e] = val[ks][4 * t + e] * rstd * gm[e] + bt[e];
+        }
+        bf[ks] = res_split8(v);
       }
-      bf[ks] = res_split8(v);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          float a0 = raw[ks][t][0], a1 = raw[ks][t][1], a2 = raw[ks][t][2], a3 = raw[ks][t][3];
+          res_transpose4(a0, a1, a2, a3);
+          v[4 * t] = a0; v[4 * t + 1] = a1; v[4 * t + 2] = a2; v[4 * t + 3] = a3;
+        }
+        bf[ks] = res_split8(v);
+      }
     }
     const int o = pir_fastdiv(active ? my : end - 1, p.magic_nbpi), nb = ((active ? my : end - 1) - o * p.nbpi) * 32;
     const __amdgpu_buffer_rsrc_t yrs = pir_make_rsrc(g.Y + (long)o * g.y_s1, active ? ybytes : 0u);   // idle wave: every store dropped
@@ -392,7 +435,9 @@ void gemm_nn_bst_kernel(BstArgs p) {
       // weight fragments read during j - 1, reads those of j + 1, issues the load of one 16-byte unit of the NEXT panel
       // and writes the unit issued PD iterations earlier into the other LDS buffer.
       constexpr int NIT = (TP / NT) * KS;
-      constexpr int PD = NIT / 2;   // iterations between the load of a panel unit and its LDS write (an L2 round trip under load)
+      // iterations between the load of a panel unit and its LDS write (an L2 round trip under load); the LayerNorm
+      // variant has fewer registers to park units in
+      constexpr int PD = LN ? (NIT / 6 > 2 ? NIT / 6 : 2) : NIT / 2;
       bf16x8 ah[NT], am[NT], al[NT];
       auto read_a = [&](int j) {
         const int pair = j / KS, ks = j % KS;
@@ -557,7 +602,7 @@ static bool res_plan(const pir_gemm_nn_t& g, ResPlan& pl) {
   return true;
 }
 
-static bool bst_plan(const pir_gemm_nn_t& g, BstArgs& a, int& grid) {
+static bool bst_plan(const pir_gemm_nn_t& g, BstArgs& a, int& grid, bool ln = false) {
   if (g_bst_mode == 0) return false;
   if (g.O2 != 1 || g.N % 32 != 0 || g.N < 32 || g.rowscale != nullptr || g.R != nullptr) return false;
   if (g.A3 == nullptr || g.a_s1 != 0 || g.a_s2 != 0) return false;
@@ -565,8 +610,9 @@ static bool bst_plan(const pir_gemm_nn_t& g, BstArgs& a, int& grid) {
   if (g.a3_kp != kp || (kp != 48 && kp != 96)) return false;
   // automatic use where the A/B over the step's shapes shows a gain (tools/resident_ab.py, profiles/r03_resident_ab.txt):
   // project_in forward (M = 254 / 510) at the 128^2 and 64^2 levels, project_out input gradient (M = 255) at 64^2
-  if (g_bst_mode < 0 && !(g.M >= 384 || (g.M >= 250 && g.M <= 256 && (kp == 48 || g.N <= 4096)))) return false;
-  if (g_bst_mode < 0 && g.N < 4096) return false;
+  if (!ln && g_bst_mode < 0 && !(g.M >= 384 || (g.M >= 250 && g.M <= 256 && (kp == 48 || g.N <= 4096)))) return false;
+  if (!ln && g_bst_mode < 0 && g.N < 4096) return false;
+  if (ln && (g.K != kp || g.M < 96)) return false;           // the fused LayerNorm needs all of K in the wave: no k tail
   if ((reinterpret_cast<uintptr_t>(g.Y) & 15) || g.ldy % 4 || g.y_s1 % 4) return false;
   if (g.R && ((reinterpret_cast<uintptr_t>(g.R) & 15) || g.ldr % 4 || g.r_s1 % 4)) return false;
   if ((reinterpret_cast<uintptr_t>(g.X) & 15) || g.ldx % 4 || g.x_s1 % 4) return false;
@@ -588,10 +634,19 @@ static bool bst_plan(const pir_gemm_nn_t& g, BstArgs& a, int& grid) {
   return true;
 }
 
-int pir_nn_bst_launch(const pir_gemm_nn_t* g, hipStream_t s) {
+int pir_nn_bst_launch(const pir_gemm_nn_t* g, hipStream_t s, const float* ln_w = nullptr, const float* ln_b = nullptr) {
   BstArgs a;
   int grid = 0;
-  if (!bst_plan(*g, a, grid)) return 1000;
+  const bool ln = ln_w != nullptr;
+  if (!bst_plan(*g, a, grid, ln)) return 1000;
+  a.ln_w = ln_w; a.ln_b = ln_b;
+  if (ln) {
+    const bool q96 = (long)a.panels * 96 >= g->M && (long)a.panels * 96 < pir_cdiv(g->M, 128) * 128 && g->a3_kp == 96;
+    if (g->a3_kp == 96 && q96) hipLaunchKernelGGL((gemm_nn_bst_kernel<6, 1, 3, true>), dim3((unsigned)grid), dim3(512), 0, s, a);
+    else if (g->a3_kp == 96) hipLaunchKernelGGL((gemm_nn_bst_kernel<6, 1, 4, true>), dim3((unsigned)grid), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((gemm_nn_bst_kernel<3, 2, 4, true>), dim3((unsigned)grid), dim3(512), 0, s, a);
+    return pir_launch_status();
+  }
   const bool p96 = (long)a.panels * 96 >= g->M && (long)a.panels * 96 < pir_cdiv(g->M, 128) * 128 && g->a3_kp == 96;
   if (g->a3_kp == 96 && p96) hipLaunchKernelGGL((gemm_nn_bst_kernel<6, 1, 3>), dim3((unsigned)grid), dim3(512), 0, s, a);
   else if (g->a3_kp == 96) hipLaunchKernelGGL((gemm_nn_bst_kernel<6, 1, 4>), dim3((unsigned)grid), dim3(512), 0, s, a);
@@ -606,6 +661,20 @@ int pir_nn_res_kind(const pir_gemm_nn_t* a) {
   if (bst_plan(*a, b, grid)) return 2;
   ResPlan pl;
   return res_plan(*a, pl) ? 1 : 0;
+}
+
+// y = W LayerNorm(x) for the no_grad forward: 1000 = shape not served (nothing launched)
+extern "C" int pir_ln_conv1x1_fwd(const float* x, long x_bs, const float* ln_w, const float* ln_b, const void* A3, int a3_kp,
+                                  float* y, long y_bs, int B, int M, int K, int HW, pir_stream_t stream) {
+  PIR_CHECK_ARG(x && ln_w && ln_b && A3 && y && B > 0 && M > 0 && K > 0 && HW > 0);
+  pir_gemm_nn_t g;
+  g.A = nullptr; g.a_s1 = g.a_s2 = 0; g.a_sm = K; g.a_sk = 1;
+  g.X = x; g.x_s1 = x_bs; g.x_s2 = 0; g.ldx = HW;
+  g.Y = y; g.y_s1 = y_bs; g.y_s2 = 0; g.ldy = HW;
+  g.R = nullptr; g.r_s1 = g.r_s2 = 0; g.ldr = 0;
+  g.rowscale = nullptr; g.rs_s1 = g.rs_s2 = 0;
+  g.M = M; g.K = K; g.N = HW; g.O1 = B; g.O2 = 1; g.A3 = A3; g.a3_kp = a3_kp;
+  return pir_nn_bst_launch(&g, (hipStream_t)stream, ln_w, ln_b);
 }
 
 int pir_nn_res_launch(const pir_gemm_nn_t* a, hipStream_t s) {

@@ -209,7 +209,7 @@ class TransformerBlock(nn.Module):
         return ops.TransformerBlockFn.apply(
             x, self.norm1.body.weight, getattr(self.norm1.body, "bias", None), a.temperature, a.qkv.weight,
             a.qkv_dwconv.weight, a.project_out.weight, self.norm2.body.weight, getattr(self.norm2.body, "bias", None),
-            f.project_in.weight, f.dwconv.weight, f.project_out.weight, a.num_heads)
+            f.project_in.weight, f.dwconv.weight, f.project_out.weight, a.num_heads, not torch.is_grad_enabled())
 
 
 ##########################################################################

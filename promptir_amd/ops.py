@@ -333,6 +333,25 @@ def conv1x1_forward(x: torch.Tensor, w: torch.Tensor, residual: Optional[torch.T
     return out
 
 
+def ln_conv1x1_forward(x: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, w: torch.Tensor) -> Optional[torch.Tensor]:
+    """y[b] = W LayerNorm_c(x[b]) with the channel LayerNorm applied on load (pir_ln_conv1x1_fwd): the normalised tensor
+    is never written.  For the no_grad forward (nothing needs it afterwards).  None when the kernel does not serve the
+    shape - the caller then runs layernorm_forward + conv1x1_forward."""
+    if not USE_X3 or ln_b is None:
+        return None
+    x = _planes(x)
+    b, cin, h, wd = x.shape
+    cout = w.shape[0]
+    a3, kp = _split_weight(w, dgrad=False)
+    y = torch.empty((b, cout, h, wd), dtype=torch.float32, device=x.device)
+    st = lib.pir_ln_conv1x1_fwd(x.data_ptr(), _bs(x), ln_w.data_ptr(), ln_b.data_ptr(), a3.data_ptr(), kp, y.data_ptr(),
+                                _bs(y), b, cout, cin, h * wd, _stream())
+    if st == 1000:
+        return None
+    check(st, "pir_ln_conv1x1_fwd")
+    return y
+
+
 def conv1x1_dgrad(dy: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dx[b] = W^T dy[b]."""
     dy = _planes(dy)
@@ -870,6 +889,7 @@ class MdtaCoreFn(torch.autograd.Function):
 
 USE_SIDE_STREAM = _os.environ.get("PIR_SIDE_STREAM", "1") != "0"   # default for callers outside a trainer
 MDTA_FOLD = _os.environ.get("PIR_MDTA_FOLD", "1") != "0"             # fold attn @ v into project_out (TransformerBlockFn)
+LN_FOLD = _os.environ.get("PIR_LN_FOLD", "1") != "0"                 # LayerNorm applied on load in the no_grad forward
 MDTA_DQK = _os.environ.get("PIR_MDTA_DQK", "1") != "0"               # dq and dk from one pass over q and k (mdta_dqk.hip)
 MDTA_FOLD_MIN_HW = int(_os.environ.get("PIR_MDTA_FOLD_MIN_HW", "4096"))   # ... at the 64^2 / 128^2 levels (below, the
 # C x C x c products it adds cost as much as the launch-bound GEMMs it removes: bench A/B, round 2)
@@ -943,10 +963,18 @@ class TransformerBlockFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, temperature, wqkv, wdw1, wproj, n2w, n2b, win, wdw2, wout, heads):
+    def forward(ctx, x, n1w, n1b, temperature, wqkv, wdw1, wproj, n2w, n2b, win, wdw2, wout, heads, no_grad=False):
         _require_gpu(x, n1w, n1b, temperature, wqkv, wdw1, wproj, n2w, n2b, win, wdw2, wout)
-        xn1, m1, r1 = layernorm_forward(x, n1w, n1b)
-        qkv0 = conv1x1_forward(xn1, wqkv)
+        # no_grad forward (inference, tiled restoration): nothing is saved, so the LayerNorms can be applied as the
+        # consuming 1x1 convolution loads its activations (pir_ln_conv1x1_fwd) wherever that kernel serves the shape
+        # (grad mode is always off INSIDE an autograd Function's forward, and needs_input_grad ignores it: the caller
+        # passes `no_grad` = not torch.is_grad_enabled())
+        infer = LN_FOLD and bool(no_grad)
+        qkv0 = ln_conv1x1_forward(x, n1w, n1b, wqkv) if infer else None
+        xn1 = m1 = r1 = None
+        if qkv0 is None:
+            xn1, m1, r1 = layernorm_forward(x, n1w, n1b)
+            qkv0 = conv1x1_forward(xn1, wqkv)
         qkv, sumsq = dwconv_sumsq_forward(qkv0, wdw1, 2 * x.shape[1])   # q / k norms from the stencil's own pass
         attn, gram, sumsq = mdta_attn_forward(qkv, temperature, heads, sumsq)
         fold = MDTA_FOLD and x.shape[2] * x.shape[3] >= MDTA_FOLD_MIN_HW
@@ -959,10 +987,15 @@ class TransformerBlockFn(torch.autograd.Function):
             gemm_nn(attn, (heads * c_ * c_, c_ * c_), c_, 1, qkv, 2 * c_all * hw_, (_bs(qkv), c_ * hw_), hw_,
                     out, 0, (c_all * hw_, c_ * hw_), hw_, c_, c_, hw_, b_, heads)
             x1 = conv1x1_forward(out, wproj, residual=x)
-        xn2, m2, r2 = layernorm_forward(x1, n2w, n2b)
-        h0 = conv1x1_forward(xn2, win)
+        h0 = ln_conv1x1_forward(x1, n2w, n2b, win) if infer else None
+        xn2 = m2 = r2 = None
+        if h0 is None:
+            xn2, m2, r2 = layernorm_forward(x1, n2w, n2b)
+            h0 = conv1x1_forward(xn2, win)
         g = dwconv_gate_forward(h0, wdw2)
         x2 = conv1x1_forward(g, wout, residual=x1)
+        if infer:
+            return x2
         ctx.heads = heads
         ctx.fold = fold
         ctx.with_bias = (n1b is not None, n2b is not None)
@@ -1009,7 +1042,7 @@ class TransformerBlockFn(torch.autograd.Function):
         return (dx, _ret(d_n1w, s_n1w), _ret(d_n1b, s_n1b) if ctx.with_bias[0] else None, _ret(d_temp, s_t),
                 _ret(d_wqkv, s_qkv), _ret(d_wdw1, s_dw1), _ret(d_wproj, s_proj),
                 _ret(d_n2w, s_n2w), _ret(d_n2b, s_n2b) if ctx.with_bias[1] else None,
-                _ret(d_win, s_in), _ret(d_wdw2, s_dw2), _ret(d_wout, s_out), None)
+                _ret(d_win, s_in), _ret(d_wdw2, s_dw2), _ret(d_wout, s_out), None, None)
 
 
 class PixelUnshuffleFn(torch.autograd.Function):

@@ -162,6 +162,30 @@ def test_k_tail_never_multiplies_what_lies_behind_the_operand(b, cin, cout, h, w
         close(y3, F.conv2d(x, w3, padding=1))
 
 
+@pytest.mark.parametrize("b,c,cout,h,w", [(2, 96, 288, 16, 16), (3, 48, 254, 8, 16), (2, 96, 510, 16, 8), (1, 96, 288, 128, 128),
+                                          (9, 48, 144, 16, 16), (2, 96, 100, 8, 8)])
+def test_layernorm_applied_on_load_in_the_no_grad_forward(b, c, cout, h, w):
+    """pir_ln_conv1x1_fwd (the B-stationary kernel with the channel LayerNorm applied as it loads its activations) vs
+    LayerNorm + 1x1 convolution on the CPU and vs the two separate HIP kernels; ragged row counts, several rounds."""
+    from oracle.promptir_ref import layer_norm
+    from promptir_amd import _lib, ops
+
+    x, wt = rnd("x", b, c, h, w) * 3 + 0.5, rnd("w", cout, c, 1, 1)
+    gam, bet = rnd("g", c) + 1.5, rnd("b", c)
+    ref = F.conv2d(layer_norm(x, gam, bet), wt)
+    xd, wd, gd, bd = x.to(DEV), wt.to(DEV), gam.to(DEV), bet.to(DEV)
+    try:
+        assert _lib.lib.pir_tune_set(24, 1) == 0          # serve shapes below the automatic size threshold too
+        y = ops.ln_conv1x1_forward(xd, gd, bd, wd)
+    finally:
+        _lib.lib.pir_tune_set(24, -1)
+    assert y is not None
+    close(y, ref, rtol=3e-5)
+    xn, _, _ = ops.layernorm_forward(xd, gd, bd)
+    close(y, ops.conv1x1_forward(xn, wd).cpu(), rtol=1e-5)
+    assert ops.ln_conv1x1_forward(xd, gd, None, wd) is None      # BiasFree keeps the separate kernels
+
+
 def test_persistent_gemm_kernels_are_selected_for_the_config3_shapes():
     """The automatic plan takes the persistent kernels for the batch-32 shapes the A/B showed a gain on, and those
     launches agree with the tiled kernel bit for bit at full size (batch 32 x 128 x 128: eight rounds per workgroup)."""

@@ -127,3 +127,41 @@ def test_graphed_forward_matches_eager():
         with torch.no_grad():
             ref = net(x)
         assert torch.equal(g(x), ref)
+
+
+def test_no_grad_forward_with_folded_layernorms_equals_the_training_forward():
+    """Under torch.no_grad() the TransformerBlock applies its LayerNorms inside the consuming 1x1 convolutions where the
+    persistent kernel serves the shape (batch 8 x 128 x 128: the 128^2 levels, BASELINE config 2's workload); the result
+    must be the training-mode forward's to rounding, and the reference's to the north_star bar."""
+    import json
+
+    from net.model import PromptIR
+    from promptir_amd import _lib, ops
+
+    z = util.load_npz("model_small_128.npz")
+    ctor = json.loads(str(z["ctor"]))
+    net = PromptIR(**ctor)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(util.params_for(shapes, int(z["seed"])))
+    DEV = torch.device("cuda:0")
+    net.to(DEV)
+    x1 = torch.from_numpy(z["x"]).to(DEV)
+    x = x1.repeat(8, 1, 1, 1)
+    calls = []
+    orig = ops.ln_conv1x1_forward
+
+    def spy(*a):
+        out = orig(*a)
+        calls.append(out is not None)
+        return out
+
+    ops.ln_conv1x1_forward = spy
+    try:
+        with torch.no_grad():
+            y_inf = net(x)
+    finally:
+        ops.ln_conv1x1_forward = orig
+    assert any(calls), "the fused LayerNorm path was never taken"
+    y_train = net(x)
+    assert float((y_inf - y_train.detach()).abs().max()) <= 2e-6
+    assert float((y_inf[:1].cpu() - torch.from_numpy(z["y"])).abs().max()) <= 1e-4
