@@ -81,10 +81,24 @@ int pir_gemm_nn(const pir_gemm_nn_t* args, pir_stream_t stream);
 int pir_ln_conv1x1_fwd(const float* x, long x_bs, const float* ln_w, const float* ln_b, const void* A3, int a3_kp,
                        float* y, long y_bs, int B, int M, int K, int HW, pir_stream_t stream);
 
+/* Input gradient of a 1x1 convolution that follows a WithBias channel LayerNorm, fused with that LayerNorm's backward
+ * (round 3): dx[b] = LN'(W^T dy[b] | x[b], mean, rstd, ln_w) + dres[b], dweight, dbias of the LayerNorm
+ * (net/model.py:60-63 behind :192-196: `self.attn(self.norm1(x))`, `self.ffn(self.norm2(x))`).  The persistent
+ * C-stationary kernel (gemm_cst.hip) holds all C channels of a pixel block in one wave, so the gradient of the normalised
+ * tensor never leaves its registers (2 of the 4 + 2 C-planes of the unfused pair are not moved).  A3 = pir_split_bf16x3
+ * of W [K][C] as the input-gradient operand.  ws: at least 512 C floats.  Served for C = 96, K a multiple-of-96-or-128
+ * padded length >= 192, HW % 32 == 0, 16-byte aligned planes; returns 1000 (nothing launched) otherwise and the caller
+ * runs pir_gemm_nn + pir_layernorm_bwd. */
+int pir_conv1x1_dgrad_ln_bwd(const float* dy, long dy_bs, const void* A3, int a3_kp, int K,
+                             const float* x, long x_bs, const float* ln_w, const float* mean, const float* rstd,
+                             const float* dres, long dres_bs, float* dx, long dx_bs, float* dweight, float* dbias,
+                             float* ws, size_t ws_floats, int B, int C, int HW, pir_stream_t stream);
+
 /* Host-only query: which kernel instantiation pir_gemm_nn would launch for `args` (pointers are not dereferenced
  * except A3 != NULL).  0 = plain fp32-MFMA kernel; otherwise the bf16x3 tile plan TM*1000 + TN*100 + WM*10 + WN
  * (workgroup of WM x WN waves, each TM x TN 32x32 MFMA tiles: 3114 = 96 x 128, 3214 = 96 x 256, 2222 = 128 x 128,
- * ...); 9000 = the persistent resident-weight-panel kernel, 9100 = the persistent B-stationary kernel (gemm_res.hip).
+ * ...); 9000 = the persistent resident-weight-panel kernel, 9100 = the persistent B-stationary kernel (gemm_res.hip),
+ * 9200 = the persistent C-stationary kernel (gemm_cst.hip).
  * Negative on bad sizes.  Lets tests pin that a benchmarked shape reaches the instantiation tuned for it. */
 int pir_gemm_nn_plan(const pir_gemm_nn_t* args);
 /* out[part][k/16][m][k%16] (bf16, k padded with zeros to kp = multiple of 16) = part-th piece of the exact

@@ -959,6 +959,7 @@ extern "C" int pir_tune_set(int knob, int value) {
     case 20: return pir_nn_res_tune(knob, value);
     case 21: case 22: case 23: case 24: return pir_nn_res_tune2(knob, value);
     case 25: return pir_nt_xp_tune(knob, value);
+    case 26: return pir_nn_cst_tune(knob, value);
     default: return PIR_EINVAL;
   }
 }
@@ -966,7 +967,8 @@ extern "C" int pir_tune_set(int knob, int value) {
 extern "C" int pir_gemm_nn_plan(const pir_gemm_nn_t* a) {
   if (!a || a->M <= 0 || a->K <= 0 || a->N <= 0 || a->O1 <= 0 || a->O2 <= 0) return PIR_EINVAL;
   if (!pir_nn_x3_wanted(a, g_nn_x3)) return 0;
-  if (g_nn_cfg < 0) {   // persistent kernels of gemm_res.hip: 9000 resident weight panel, 9100 B-stationary
+  if (g_nn_cfg < 0) {   // persistent kernels: 9000 resident weight panel, 9100 B-stationary, 9200 C-stationary
+    if (pir_nn_cst_serves(a)) return 9200;
     const int kind = pir_nn_res_kind(a);
     if (kind) return kind == 2 ? 9100 : 9000;
   }
@@ -983,8 +985,10 @@ extern "C" int pir_gemm_nn(const pir_gemm_nn_t* a, pir_stream_t stream) {
   PIR_CHECK_ARG(a->R == nullptr || (long)a->M * a->ldr < 2147483647L);
   PIR_CHECK_ARG((long)(a->M - 1) * a->a_sm + (long)(a->K - 1) * a->a_sk < 2147483647L);
   if (pir_nn_x3_wanted(a, g_nn_x3)) {
-    if (g_nn_cfg < 0) {   // long pixel streams against a weight panel that fits LDS: the resident-panel kernel
-      const int st = pir_nn_res_launch(a, (hipStream_t)stream);
+    if (g_nn_cfg < 0) {   // long pixel streams: the persistent kernels (gemm_cst.hip, gemm_res.hip)
+      int st = pir_nn_cst_launch(a, (hipStream_t)stream);
+      if (st != 1000) return st;
+      st = pir_nn_res_launch(a, (hipStream_t)stream);
       if (st != 1000) return st;
     }
     return pir_nn_x3_launch(a, g_nn_cfg, (hipStream_t)stream);

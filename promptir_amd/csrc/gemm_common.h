@@ -119,6 +119,11 @@ int pir_nn_res_launch(const pir_gemm_nn_t* a, hipStream_t stream);
 int pir_nn_res_tune(int knob, int value);
 int pir_nn_res_tune2(int knob, int value);
 
+// C-stationary persistent kernel for few rows against a long k (gemm_cst.hip): 1000 = shape not served
+bool pir_nn_cst_serves(const pir_gemm_nn_t* a);
+int pir_nn_cst_launch(const pir_gemm_nn_t* a, hipStream_t stream);
+int pir_nn_cst_tune(int knob, int value);
+
 // tall x small weight gradients with the tall operand private to its wave (gemm_ntx.hip): 1000 = shape not served
 int pir_nt_xp_launch(const pir_gemm_nt_t* a, int* splits, hipStream_t stream);
 int pir_nt_xp_splits(const pir_gemm_nt_t* a);

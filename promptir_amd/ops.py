@@ -455,6 +455,29 @@ def layernorm_backward(dy, x, weight, with_bias, mean, rstd, dweight=None, dbias
     return dx, dweight, dbias
 
 
+def conv1x1_dgrad_ln_backward(dy, w, x, ln_w, mean, rstd, dweight=None, dbias=None, dres=None):
+    """Input gradient of `conv1x1(LayerNorm(x))` in one pass (gemm_cst.hip): dx = LN'(W^T dy) + dres, dweight, dbias of the
+    WithBias LayerNorm - or None where the fused kernel does not serve the shape (the caller then runs the pair)."""
+    if not (USE_X3 and DGRAD_LN):
+        return None
+    dy, x = _planes(dy), _planes(x)
+    if dres is not None:
+        dres = _planes(dres)
+    b, c, h, wd = x.shape
+    a3, kp = _split_weight(w, dgrad=True)
+    dx = torch.empty((b, c, h, wd), dtype=torch.float32, device=x.device)
+    dweight, dbias = _grad_out(ln_w, dweight), _grad_out(ln_w, dbias)
+    ws = workspace(max(512 * c, lib.pir_layernorm_bwd_ws_floats(b, c, h * wd)), x.device)
+    st = lib.pir_conv1x1_dgrad_ln_bwd(dy.data_ptr(), _bs(dy), a3.data_ptr(), kp, dy.shape[1], x.data_ptr(), _bs(x),
+                                      ln_w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dres),
+                                      _bs(dres) if dres is not None else 0, dx.data_ptr(), _bs(dx), dweight.data_ptr(),
+                                      dbias.data_ptr(), ws.data_ptr(), ws.numel(), b, c, h * wd, _stream())
+    if st == 1000:
+        return None
+    check(st, "pir_conv1x1_dgrad_ln_bwd")
+    return dx, dweight, dbias
+
+
 def dwconv_forward(x, w, flip=False, out=None):
     x = _planes(x)
     b, c, h, wd = x.shape
@@ -890,6 +913,7 @@ class MdtaCoreFn(torch.autograd.Function):
 USE_SIDE_STREAM = _os.environ.get("PIR_SIDE_STREAM", "1") != "0"   # default for callers outside a trainer
 MDTA_FOLD = _os.environ.get("PIR_MDTA_FOLD", "1") != "0"             # fold attn @ v into project_out (TransformerBlockFn)
 LN_FOLD = _os.environ.get("PIR_LN_FOLD", "1") != "0"                 # LayerNorm applied on load in the no_grad forward
+DGRAD_LN = _os.environ.get("PIR_DGRAD_LN", "1") != "0"               # input gradient + LayerNorm backward in one kernel (gemm_cst.hip)
 MDTA_DQK = _os.environ.get("PIR_MDTA_DQK", "1") != "0"               # dq and dk from one pass over q and k (mdta_dqk.hip)
 MDTA_FOLD_MIN_HW = int(_os.environ.get("PIR_MDTA_FOLD_MIN_HW", "4096"))   # ... at the 64^2 / 128^2 levels (below, the
 # C x C x c products it adds cost as much as the launch-bound GEMMs it removes: bench A/B, round 2)
@@ -1017,11 +1041,14 @@ class TransformerBlockFn(torch.autograd.Function):
         d_wout = side.wgrad(dx2, g, wout, s_out)
         dh0, d_wdw2 = gdfn_dwconv_backward(h0, wdw2, dg, s_dw2)
         del dg
-        dxn2 = conv1x1_dgrad(dh0, win)
         d_win = side.wgrad(dh0, xn2, win, s_in)
+        fused = conv1x1_dgrad_ln_backward(dh0, win, x1, n2w, m2, r2, s_n2w, s_n2b, dres=dx2) if ctx.with_bias[1] else None
+        if fused is None:
+            dxn2 = conv1x1_dgrad(dh0, win)
+            fused = layernorm_backward(dxn2, x1, n2w, ctx.with_bias[1], m2, r2, s_n2w, s_n2b, dres=dx2)
+            del dxn2
+        dx1, d_n2w, d_n2b = fused
         del dh0
-        dx1, d_n2w, d_n2b = layernorm_backward(dxn2, x1, n2w, ctx.with_bias[1], m2, r2, s_n2w, s_n2b, dres=dx2)
-        del dxn2
         # ---- MDTA branch
         if ctx.fold:
             dqkv = torch.empty_like(qkv)
@@ -1034,10 +1061,14 @@ class TransformerBlockFn(torch.autograd.Function):
             del dout
         dqkv0, d_wdw1 = dwconv_backward(dqkv, qkv0, wdw1, s_dw1)
         del dqkv
-        dxn1 = conv1x1_dgrad(dqkv0, wqkv)
         d_wqkv = side.wgrad(dqkv0, xn1, wqkv, s_qkv)
+        fused = conv1x1_dgrad_ln_backward(dqkv0, wqkv, x, n1w, m1, r1, s_n1w, s_n1b, dres=dx1) if ctx.with_bias[0] else None
+        if fused is None:
+            dxn1 = conv1x1_dgrad(dqkv0, wqkv)
+            fused = layernorm_backward(dxn1, x, n1w, ctx.with_bias[0], m1, r1, s_n1w, s_n1b, dres=dx1)
+            del dxn1
+        dx, d_n1w, d_n1b = fused
         del dqkv0
-        dx, d_n1w, d_n1b = layernorm_backward(dxn1, x, n1w, ctx.with_bias[0], m1, r1, s_n1w, s_n1b, dres=dx1)
         side.join()
         return (dx, _ret(d_n1w, s_n1w), _ret(d_n1b, s_n1b) if ctx.with_bias[0] else None, _ret(d_temp, s_t),
                 _ret(d_wqkv, s_qkv), _ret(d_wdw1, s_dw1), _ret(d_wproj, s_proj),

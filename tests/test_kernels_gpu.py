@@ -186,6 +186,64 @@ def test_layernorm_applied_on_load_in_the_no_grad_forward(b, c, cout, h, w):
     assert ops.ln_conv1x1_forward(xd, gd, None, wd) is None      # BiasFree keeps the separate kernels
 
 
+@pytest.mark.parametrize("b,k,h,w,res", [(2, 288, 32, 32, True), (3, 510, 8, 20, True), (2, 288, 16, 16, False), (1, 510, 64, 64, True),
+                                         (5, 255, 8, 8, True)])
+def test_input_gradient_fused_with_the_layernorm_backward(b, k, h, w, res):
+    """pir_conv1x1_dgrad_ln_bwd (C-stationary kernel, LayerNorm backward in the store tail) vs the separate input-gradient
+    GEMM + pir_layernorm_bwd, and vs autograd of conv1x1(LayerNorm(x)) on the CPU; idle waves (15 column blocks), several
+    rounds, no residual gradient, a non-contiguous batch stride."""
+    from oracle.promptir_ref import layer_norm
+    from promptir_amd import ops
+
+    c = 96
+    x = (rnd("x", b, c, h, w) * 3 + 0.5).requires_grad_(True)
+    wt, gam, bet = rnd("w", k, c, 1, 1), (rnd("g", c) + 1.5).requires_grad_(True), rnd("b", c).requires_grad_(True)
+    dy, dres = rnd("dy", b, k, h, w), rnd("dres", b, c, h, w)
+    F.conv2d(layer_norm(x, gam, bet), wt).backward(dy)
+    ref_dx = x.grad + (dres if res else 0)
+    xd, wd, gd, bd = x.detach().to(DEV), wt.to(DEV), gam.detach().to(DEV), bet.detach().to(DEV)
+    big = torch.zeros(b, k + 7, h, w, device=DEV)          # dy as a channel slice of a larger tensor: free batch stride
+    big[:, :k] = dy.to(DEV)
+    dyd, dresd = big[:, :k], (dres.to(DEV) if res else None)
+    _, mean, rstd = ops.layernorm_forward(xd, gd, bd)
+    got = ops.conv1x1_dgrad_ln_backward(dyd, wd, xd, gd, mean, rstd, dres=dresd)
+    assert got is not None
+    dx, dg, db = got
+    close(dx, ref_dx, rtol=3e-5)
+    close(dg, gam.grad, rtol=3e-5)
+    close(db, bet.grad, rtol=3e-5)
+    dxn = ops.conv1x1_dgrad(dyd, wd)
+    dx2, dg2, db2 = ops.layernorm_backward(dxn, xd, gd, True, mean, rstd, dres=dresd)
+    close(dx, dx2.cpu(), rtol=1e-5)
+    close(dg, dg2.cpu(), rtol=1e-5)
+    close(db, db2.cpu(), rtol=1e-5)
+
+
+@pytest.mark.parametrize("b,k,h,w,res,dgrad", [(2, 510, 32, 32, False, True), (3, 255, 8, 20, True, False), (1, 288, 64, 64, False, True),
+                                               (5, 288, 8, 8, True, False)])
+def test_c_stationary_gemm_equals_the_tiled_kernel(b, k, h, w, res, dgrad):
+    """gemm_cst.hip (knob 26; 96 output rows against a long k) against the tiled bf16x3 kernel, bit for bit: residual,
+    k tails (255, 510), idle waves in the last workgroup (15 and 10 column blocks), several rounds."""
+    from promptir_amd import _lib, ops
+
+    L = _lib.lib
+    c = 96
+    wt = rnd("w", k, c, 1, 1).to(DEV) if dgrad else rnd("w", c, k, 1, 1).to(DEV)
+    x = rnd("x", b, k, h, w).to(DEV)
+    r = rnd("r", b, c, h, w).to(DEV) if res else None
+    call = (lambda: ops.conv1x1_dgrad(x, wt)) if dgrad else (lambda: ops.conv1x1_forward(x, wt, r))
+    try:
+        L.pir_tune_set(26, 1)
+        y_cst = call()
+        L.pir_tune_set(26, 0)
+        y_tiled = call()
+    finally:
+        L.pir_tune_set(26, -1)
+    assert torch.equal(y_cst, y_tiled)
+    ref = F.conv_transpose2d(x.cpu(), wt.cpu()) if dgrad else F.conv2d(x.cpu(), wt.cpu()) + (r.cpu() if res else 0)
+    close(y_cst, ref)
+
+
 def test_persistent_gemm_kernels_are_selected_for_the_config3_shapes():
     """The automatic plan takes the persistent kernels for the batch-32 shapes the A/B showed a gain on, and those
     launches agree with the tiled kernel bit for bit at full size (batch 32 x 128 x 128: eight rounds per workgroup)."""
