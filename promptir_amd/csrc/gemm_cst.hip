@@ -301,11 +301,11 @@ void gemm_nn_cst_kernel(CstArgs p) {
         }
       }
     __syncthreads();
-    if (tid < 2 * BM) {
+    for (int t = tid; t < 2 * BM; t += T) {
       float sum = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) sum += red[w * 2 * BM + tid];
-      p.ws[(long)blockIdx.x * 2 * BM + tid] = sum;
+      for (int w = 0; w < NW; ++w) sum += red[w * 2 * BM + t];
+      p.ws[(long)blockIdx.x * 2 * BM + t] = sum;
     }
   }
 }
@@ -316,11 +316,16 @@ bool cst_plan(const pir_gemm_nn_t& g, CstArgs& a, int& grid, int& pk, bool lnb =
   if (g_cst_mode == 0 && !lnb) return false;
   if (g.O2 != 1 || g.N % 32 != 0 || g.N < 32 || g.rowscale != nullptr) return false;
   if (g.A3 == nullptr || g.a_s1 != 0 || g.a_s2 != 0) return false;
-  if (g.M != 96) return false;
+  if (g.M != 96 && g.M != 192) return false;
   const int kp = (int)(pir_cdiv(g.K, 16) * 16), ks = kp / 16;
   if (g.a3_kp != kp || ks < 12) return false;
-  pk = ks % 8 == 0 ? 8 : ks % 6 == 0 ? 6 : 0;
+  // 96 rows: eight waves, panels of 8 or 6 k-steps; 192 rows: four waves (all registers of a SIMD to one wave), panels of 4
+  const int nw = g.M == 96 ? 8 : 4;
+  pk = g.M == 192 ? (ks % 4 == 0 ? 4 : 0) : ks % 8 == 0 ? 8 : ks % 6 == 0 ? 6 : 0;
   if (!pk) return false;
+  // plain 192-row products (32^2 level) gain nothing over the tiled kernel (tools/cst_ab.py: 0.99-1.05 at batch 32, half
+  // the chip idle at batch 16): automatic only inside the fused LayerNorm backward
+  if (g.M == 192 && !lnb && g_cst_mode < 0) return false;
   if ((reinterpret_cast<uintptr_t>(g.Y) & 15) || g.ldy % 4 || g.y_s1 % 4) return false;
   if (g.R && ((reinterpret_cast<uintptr_t>(g.R) & 15) || g.ldr % 4 || g.r_s1 % 4)) return false;
   if ((reinterpret_cast<uintptr_t>(g.X) & 15) || g.ldx % 4 || g.x_s1 % 4) return false;
@@ -333,7 +338,7 @@ bool cst_plan(const pir_gemm_nn_t& g, CstArgs& a, int& grid, int& pk, bool lnb =
   a.blocks_total = g.O1 * a.nbpi;
   if ((long)a.blocks_total * (a.nbpi > 1 ? a.nbpi : 2) >= (1L << 32)) return false;
   a.panels = ks / pk;
-  const long per = pir_cdiv(pir_cdiv(a.blocks_total, (long)PIR_NUM_CU), 8) * 8;   // one eight-wave workgroup per CU
+  const long per = pir_cdiv(pir_cdiv(a.blocks_total, (long)PIR_NUM_CU), nw) * nw;   // one workgroup per CU
   a.per_wg = (int)per;
   grid = (int)pir_cdiv(a.blocks_total, per);
   return true;
@@ -355,7 +360,8 @@ bool pir_nn_cst_serves(const pir_gemm_nn_t* g) {
 int pir_nn_cst_launch(const pir_gemm_nn_t* g, hipStream_t s) {
   CstArgs a; int grid = 0, pk = 0;
   if (!cst_plan(*g, a, grid, pk)) return 1000;
-  if (pk == 8) hipLaunchKernelGGL((gemm_nn_cst_kernel<3, 8, 8>), dim3((unsigned)grid), dim3(512), 0, s, a);
+  if (g->M == 192) hipLaunchKernelGGL((gemm_nn_cst_kernel<6, 4, 4>), dim3((unsigned)grid), dim3(256), 0, s, a);
+  else if (pk == 8) hipLaunchKernelGGL((gemm_nn_cst_kernel<3, 8, 8>), dim3((unsigned)grid), dim3(512), 0, s, a);
   else hipLaunchKernelGGL((gemm_nn_cst_kernel<3, 6, 8>), dim3((unsigned)grid), dim3(512), 0, s, a);
   return pir_launch_status();
 }
@@ -385,7 +391,8 @@ extern "C" int pir_conv1x1_dgrad_ln_bwd(const float* dy, long dy_bs, const void*
   if ((size_t)grid * 2 * C > ws_floats) return PIR_ENOMEM;
   a.lx = x; a.lx_bs = x_bs; a.mean = mean; a.rstd = rstd; a.gamma = ln_w; a.dres = dres; a.dres_bs = dres_bs; a.ws = ws;
   hipStream_t s = (hipStream_t)stream;
-  if (pk == 8) hipLaunchKernelGGL((gemm_nn_cst_kernel<3, 8, 8, true>), dim3((unsigned)grid), dim3(512), 0, s, a);
+  if (C == 192) hipLaunchKernelGGL((gemm_nn_cst_kernel<6, 4, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
+  else if (pk == 8) hipLaunchKernelGGL((gemm_nn_cst_kernel<3, 8, 8, true>), dim3((unsigned)grid), dim3(512), 0, s, a);
   else hipLaunchKernelGGL((gemm_nn_cst_kernel<3, 6, 8, true>), dim3((unsigned)grid), dim3(512), 0, s, a);
   const int st = pir_launch_status();
   if (st) return st;

@@ -186,16 +186,16 @@ def test_layernorm_applied_on_load_in_the_no_grad_forward(b, c, cout, h, w):
     assert ops.ln_conv1x1_forward(xd, gd, None, wd) is None      # BiasFree keeps the separate kernels
 
 
-@pytest.mark.parametrize("b,k,h,w,res", [(2, 288, 32, 32, True), (3, 510, 8, 20, True), (2, 288, 16, 16, False), (1, 510, 64, 64, True),
-                                         (5, 255, 8, 8, True)])
-def test_input_gradient_fused_with_the_layernorm_backward(b, k, h, w, res):
+@pytest.mark.parametrize("b,c,k,h,w,res", [(2, 96, 288, 32, 32, True), (3, 96, 510, 8, 20, True), (2, 96, 288, 16, 16, False),
+                                           (1, 96, 510, 64, 64, True), (5, 96, 255, 8, 8, True), (3, 192, 576, 8, 20, True),
+                                           (2, 192, 1020, 32, 32, False), (9, 192, 510, 16, 16, True)])
+def test_input_gradient_fused_with_the_layernorm_backward(b, c, k, h, w, res):
     """pir_conv1x1_dgrad_ln_bwd (C-stationary kernel, LayerNorm backward in the store tail) vs the separate input-gradient
     GEMM + pir_layernorm_bwd, and vs autograd of conv1x1(LayerNorm(x)) on the CPU; idle waves (15 column blocks), several
     rounds, no residual gradient, a non-contiguous batch stride."""
     from oracle.promptir_ref import layer_norm
     from promptir_amd import ops
 
-    c = 96
     x = (rnd("x", b, c, h, w) * 3 + 0.5).requires_grad_(True)
     wt, gam, bet = rnd("w", k, c, 1, 1), (rnd("g", c) + 1.5).requires_grad_(True), rnd("b", c).requires_grad_(True)
     dy, dres = rnd("dy", b, k, h, w), rnd("dres", b, c, h, w)
@@ -219,15 +219,16 @@ def test_input_gradient_fused_with_the_layernorm_backward(b, k, h, w, res):
     close(db, db2.cpu(), rtol=1e-5)
 
 
-@pytest.mark.parametrize("b,k,h,w,res,dgrad", [(2, 510, 32, 32, False, True), (3, 255, 8, 20, True, False), (1, 288, 64, 64, False, True),
-                                               (5, 288, 8, 8, True, False)])
-def test_c_stationary_gemm_equals_the_tiled_kernel(b, k, h, w, res, dgrad):
-    """gemm_cst.hip (knob 26; 96 output rows against a long k) against the tiled bf16x3 kernel, bit for bit: residual,
-    k tails (255, 510), idle waves in the last workgroup (15 and 10 column blocks), several rounds."""
+@pytest.mark.parametrize("b,c,k,h,w,res,dgrad", [(2, 96, 510, 32, 32, False, True), (3, 96, 255, 8, 20, True, False),
+                                                 (1, 96, 288, 64, 64, False, True), (5, 96, 288, 8, 8, True, False),
+                                                 (3, 192, 510, 8, 20, True, False), (2, 192, 1020, 32, 32, False, True),
+                                                 (9, 192, 576, 16, 16, False, True)])
+def test_c_stationary_gemm_equals_the_tiled_kernel(b, c, k, h, w, res, dgrad):
+    """gemm_cst.hip (knob 26; 96 or 192 output rows against a long k) against the tiled bf16x3 kernel, bit for bit: residual,
+    k tails (255, 510, 1020), idle waves in the last workgroup (15 and 10 column blocks), several rounds."""
     from promptir_amd import _lib, ops
 
     L = _lib.lib
-    c = 96
     wt = rnd("w", k, c, 1, 1).to(DEV) if dgrad else rnd("w", c, k, 1, 1).to(DEV)
     x = rnd("x", b, k, h, w).to(DEV)
     r = rnd("r", b, c, h, w).to(DEV) if res else None

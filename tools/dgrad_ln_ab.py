@@ -20,9 +20,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     B = ap.parse_args().batch
     print(f"batch {B}\n{'shape':24s} | {'pair us':>9s} {'fused us':>9s} {'ratio':>6s} | fused GB/s (alg.)")
-    for S in (128, 64):
-        for tag, K in (("qkv (LN1)", 288), ("ffn_in (LN2)", 510)):
-            c = 96
+    for c, S in ((96, 128), (96, 64), (192, 32)):
+        for tag, K in (("qkv (LN1)", 3 * c), ("ffn_in (LN2)", 2 * int(c * 2.66))):
             x, w, dy, dres = r(B, c, S, S), r(K, c, 1, 1), r(B, K, S, S), r(B, c, S, S)
             gam, bet = r(c), r(c)
             _, mean, rstd = ops.layernorm_forward(x, gam, bet)
@@ -37,7 +36,7 @@ def main():
 
             t_p, t_f = timeit([pair, fused])
             by = 4.0 * S * S * B * (K + 3 * c)
-            print(f"C96 {S}^2 {tag:14s} | {t_p*1e6:9.1f} {t_f*1e6:9.1f} {t_f/t_p:6.2f} | {by/t_f/1e9:8.0f}", flush=True)
+            print(f"C{c} {S}^2 {tag:14s} | {t_p*1e6:9.1f} {t_f*1e6:9.1f} {t_f/t_p:6.2f} | {by/t_f/1e9:8.0f}", flush=True)
 
 
 if __name__ == "__main__":
