@@ -1,4 +1,4 @@
-// gemm_nn, C-STATIONARY: few output rows (M = 96 or 192) against a long k (bf16x3 split MFMA, gfx950).
+// gemm_nn, C-STATIONARY: few output rows (M = 48, 96 or 192) against a long k (bf16x3 split MFMA, gfx950).
 //
 //   Y[o][m][n] = sum_k A(m,k) X[o][k][n] (+ R[o][m][n])                       (same contract as pir_gemm_nn)
 //
@@ -46,15 +46,17 @@ __device__ __forceinline__ float cst_sum_rows(float v) {
 // LNB: the product is the gradient dy of a WithBias channel LayerNorm's output (net/model.py:60-63); a wave holds all M
 // channels of its 32 pixels, so the LayerNorm backward runs in its registers - with d = dy, xn = (x - mean) rstd,
 // g = d gamma: dx = rstd (g - mean_c(g) - xn mean_c(g xn)) + dres, dgamma += d xn, dbeta += d - and dy is never written.
-template <int TM, int PK, int NW, bool LNB = false>
+// MR: the real row count (48: two 32-row MFMA tiles whose rows 48 .. 63 are zero in LDS and dropped at the store)
+template <int TM, int PK, int NW, bool LNB = false, int MR = 32 * TM>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4)))
 void gemm_nn_cst_kernel(CstArgs p) {
   constexpr int BM = 32 * TM, T = NW * 64, PF = PK % 4 == 0 ? 4 : 3;
+  constexpr int PUG = PK * MR * 2;            // 16-byte units per part of a panel in global memory (MR rows)
   constexpr int PU = PK * BM * 2;             // 16-byte units per part of a panel
   constexpr int PANEL = 3 * PU;
   constexpr int NLD = (PANEL + T - 1) / T;    // units per thread and panel
   constexpr int NIT = PK * TM;                // (k-step, row tile) iterations per panel
-  constexpr int PD = LNB ? NIT / 4 : NIT / 2; // iterations between the load of a panel unit and its LDS write (LNB: fewer registers to park units in)
+  constexpr int PD = LNB ? (NIT / 4 > 0 ? NIT / 4 : 1) : NIT / 2; // iterations between the load of a panel unit and its LDS write (LNB: fewer registers to park units in)
   static_assert(PK % PF == 0 && NLD <= NIT - 1, "panel staging");
   __shared__ bf16x8 smem[2 * PANEL];
   const pir_gemm_nn_t& g = p.g;
@@ -69,21 +71,21 @@ void gemm_nn_cst_kernel(CstArgs p) {
   const unsigned ybytes = (unsigned)((((long)g.M - 1) * g.ldy + g.N) * 4);
   const unsigned rbytes = (unsigned)((((long)g.M - 1) * g.ldr + g.N) * 4);
   const bool has_r = g.R != nullptr;
-  const __amdgpu_buffer_rsrc_t ars = pir_make_rsrc(g.A3, (unsigned)(6L * BM * g.a3_kp));
-  const int part_bytes = BM * g.a3_kp * 2;
+  const __amdgpu_buffer_rsrc_t ars = pir_make_rsrc(g.A3, (unsigned)(6L * MR * g.a3_kp));
+  const int part_bytes = MR * g.a3_kp * 2;
 
   // ---- weight panel `pi` (k-steps PK pi ..): pir_split_bf16x3 stores [part][k-step][row][k-group][8 bf16], so the three
   // parts of a panel are three contiguous runs of PU units; unit (idx, thread) -> registers -> LDS [part][k-step][k-group][row]
   auto panel_load = [&](int pi, int idx) {
-    const int u0 = tid + idx * T, u = (PANEL % T == 0 || u0 < PANEL) ? u0 : 0;
-    const int part = (u >= PU) + (u >= 2 * PU), w = u - part * PU;
-    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ars, part * part_bytes + w * 16, pi * (PK * BM * 32), 0));
+    const int u0 = tid + idx * T, u = ((3 * PUG) % T == 0 || u0 < 3 * PUG) ? u0 : 0;
+    const int part = (u >= PUG) + (u >= 2 * PUG), w = u - part * PUG;
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ars, part * part_bytes + w * 16, pi * (PK * MR * 32), 0));
   };
   auto panel_store = [&](int buf, int idx, const bf16x8& v) {
     const int u = tid + idx * T;
-    const int part = (u >= PU) + (u >= 2 * PU), w = u - part * PU;
-    const int kg = w & 1, rw = (w >> 1) % BM, ksl = (w >> 1) / BM;
-    if (PANEL % T == 0 || u < PANEL) smem[buf * PANEL + part * PU + (ksl * 2 + kg) * BM + rw] = v;
+    const int part = (u >= PUG) + (u >= 2 * PUG), w = u - part * PUG;
+    const int kg = w & 1, rw = (w >> 1) % MR, ksl = (w >> 1) / MR;
+    if ((3 * PUG) % T == 0 || u < 3 * PUG) smem[buf * PANEL + part * PU + (ksl * 2 + kg) * BM + rw] = v;
   };
 
   // ---- activations of a column block: 2 x 16-byte loads per k-step (layout: gemm_nn_res_kernel)
@@ -114,6 +116,11 @@ void gemm_nn_cst_kernel(CstArgs p) {
   };
 
   // first panel, first k-steps of the first block
+  if constexpr (MR < BM) {   // the padding rows of both buffers stay zero for the whole kernel
+    const bf16x8 z = {};
+    for (int u = tid; u < 2 * PANEL; u += T) smem[u] = z;
+    __syncthreads();
+  }
 #pragma unroll
   for (int idx = 0; idx < NLD; ++idx) panel_store(0, idx, panel_load(0, idx));
   int my = begin + wid;                       // this wave's column block in the current round (clamped by cols())
@@ -130,7 +137,7 @@ void gemm_nn_cst_kernel(CstArgs p) {
   __shared__ float gsm[LNB ? BM : 1];
   float pw[TM][4], pb[TM][4];
   if constexpr (LNB) {
-    if (tid < BM) gsm[tid] = p.gamma[tid];       // (visible behind the prologue's barrier)
+    if (tid < BM) gsm[tid] = tid < MR ? p.gamma[tid] : 0.f;   // (visible behind the prologue's barrier)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -201,7 +208,7 @@ void gemm_nn_cst_kernel(CstArgs p) {
       const __amdgpu_buffer_rsrc_t yrs = pir_make_rsrc(g.Y + (long)o * g.y_s1, active ? ybytes : 0u);
       const int vy = ((4 * h + qj) * ldy + nb + 4 * qk) * 4;
       const int n4 = g.N * 4;
-      const unsigned pbytes = (unsigned)((long)BM * n4);
+      const unsigned pbytes = (unsigned)((long)MR * n4);
       const __amdgpu_buffer_rsrc_t xrs = pir_make_rsrc(p.lx + (long)o * p.lx_bs, pbytes);
       const __amdgpu_buffer_rsrc_t drs = pir_make_rsrc(p.dres ? p.dres + (long)o * p.dres_bs : p.lx, p.dres ? pbytes : 0u);
       const __amdgpu_buffer_rsrc_t mrs = pir_make_rsrc(p.mean + (long)o * g.N, (unsigned)n4);
@@ -234,7 +241,7 @@ void gemm_nn_cst_kernel(CstArgs p) {
         }
       f32x4 m1, m2;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { m1[e] = cst_sum_rows(s1[e]) * (1.f / (float)BM); m2[e] = cst_sum_rows(s2[e]) * (1.f / (float)BM); }
+      for (int e = 0; e < 4; ++e) { m1[e] = cst_sum_rows(s1[e]) * (1.f / (float)MR); m2[e] = cst_sum_rows(s2[e]) * (1.f / (float)MR); }
       // the residual gradient arrives one row tile ahead of its use (all of it at once would not fit the registers)
       f32x4 rv[2][4];
 #pragma unroll
@@ -301,11 +308,12 @@ void gemm_nn_cst_kernel(CstArgs p) {
         }
       }
     __syncthreads();
-    for (int t = tid; t < 2 * BM; t += T) {
+    for (int t = tid; t < 2 * MR; t += T) {
+      const int which = t / MR, c = t - which * MR;
       float sum = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) sum += red[w * 2 * BM + t];
-      p.ws[(long)blockIdx.x * 2 * BM + t] = sum;
+      for (int w = 0; w < NW; ++w) sum += red[(w * 2 + which) * BM + c];
+      p.ws[(long)blockIdx.x * 2 * MR + t] = sum;
     }
   }
 }
@@ -316,12 +324,12 @@ bool cst_plan(const pir_gemm_nn_t& g, CstArgs& a, int& grid, int& pk, bool lnb =
   if (g_cst_mode == 0 && !lnb) return false;
   if (g.O2 != 1 || g.N % 32 != 0 || g.N < 32 || g.rowscale != nullptr) return false;
   if (g.A3 == nullptr || g.a_s1 != 0 || g.a_s2 != 0) return false;
-  if (g.M != 96 && g.M != 192) return false;
+  if (g.M != 96 && g.M != 192 && g.M != 48) return false;
   const int kp = (int)(pir_cdiv(g.K, 16) * 16), ks = kp / 16;
-  if (g.a3_kp != kp || ks < 12) return false;
+  if (g.a3_kp != kp || ks < (g.M == 48 ? 8 : 12)) return false;
   // 96 rows: eight waves, panels of 8 or 6 k-steps; 192 rows: four waves (all registers of a SIMD to one wave), panels of 4
   const int nw = g.M == 96 ? 8 : 4;
-  pk = g.M == 192 ? (ks % 4 == 0 ? 4 : 0) : ks % 8 == 0 ? 8 : ks % 6 == 0 ? 6 : 0;
+  pk = g.M == 192 ? (ks % 4 == 0 ? 4 : 0) : g.M == 48 ? (ks % 8 == 0 ? 8 : ks == 9 ? 9 : 0) : ks % 8 == 0 ? 8 : ks % 6 == 0 ? 6 : 0;
   if (!pk) return false;
   // plain 192-row products (32^2 level) gain nothing over the tiled kernel (tools/cst_ab.py: 0.99-1.05 at batch 32, half
   // the chip idle at batch 16): automatic only inside the fused LayerNorm backward
@@ -360,7 +368,10 @@ bool pir_nn_cst_serves(const pir_gemm_nn_t* g) {
 int pir_nn_cst_launch(const pir_gemm_nn_t* g, hipStream_t s) {
   CstArgs a; int grid = 0, pk = 0;
   if (!cst_plan(*g, a, grid, pk)) return 1000;
-  if (g->M == 192) hipLaunchKernelGGL((gemm_nn_cst_kernel<6, 4, 4>), dim3((unsigned)grid), dim3(256), 0, s, a);
+  if (g->M == 48 && pk == 9) hipLaunchKernelGGL((gemm_nn_cst_kernel<2, 9, 8, false, 48>), dim3((unsigned)grid), dim3(512), 0, s, a);
+  else if (g->M == 48 && pk == 8) hipLaunchKernelGGL((gemm_nn_cst_kernel<2, 8, 8, false, 48>), dim3((unsigned)grid), dim3(512), 0, s, a);
+  else if (g->M == 48) return 1000;
+  else if (g->M == 192) hipLaunchKernelGGL((gemm_nn_cst_kernel<6, 4, 4>), dim3((unsigned)grid), dim3(256), 0, s, a);
   else if (pk == 8) hipLaunchKernelGGL((gemm_nn_cst_kernel<3, 8, 8>), dim3((unsigned)grid), dim3(512), 0, s, a);
   else hipLaunchKernelGGL((gemm_nn_cst_kernel<3, 6, 8>), dim3((unsigned)grid), dim3(512), 0, s, a);
   return pir_launch_status();
@@ -391,7 +402,10 @@ extern "C" int pir_conv1x1_dgrad_ln_bwd(const float* dy, long dy_bs, const void*
   if ((size_t)grid * 2 * C > ws_floats) return PIR_ENOMEM;
   a.lx = x; a.lx_bs = x_bs; a.mean = mean; a.rstd = rstd; a.gamma = ln_w; a.dres = dres; a.dres_bs = dres_bs; a.ws = ws;
   hipStream_t s = (hipStream_t)stream;
-  if (C == 192) hipLaunchKernelGGL((gemm_nn_cst_kernel<6, 4, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
+  if (C == 48 && pk == 9) hipLaunchKernelGGL((gemm_nn_cst_kernel<2, 9, 8, true, 48>), dim3((unsigned)grid), dim3(512), 0, s, a);
+  else if (C == 48 && pk == 8) hipLaunchKernelGGL((gemm_nn_cst_kernel<2, 8, 8, true, 48>), dim3((unsigned)grid), dim3(512), 0, s, a);
+  else if (C == 48) return 1000;
+  else if (C == 192) hipLaunchKernelGGL((gemm_nn_cst_kernel<6, 4, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
   else if (pk == 8) hipLaunchKernelGGL((gemm_nn_cst_kernel<3, 8, 8, true>), dim3((unsigned)grid), dim3(512), 0, s, a);
   else hipLaunchKernelGGL((gemm_nn_cst_kernel<3, 6, 8, true>), dim3((unsigned)grid), dim3(512), 0, s, a);
   const int st = pir_launch_status();

@@ -188,7 +188,8 @@ def test_layernorm_applied_on_load_in_the_no_grad_forward(b, c, cout, h, w):
 
 @pytest.mark.parametrize("b,c,k,h,w,res", [(2, 96, 288, 32, 32, True), (3, 96, 510, 8, 20, True), (2, 96, 288, 16, 16, False),
                                            (1, 96, 510, 64, 64, True), (5, 96, 255, 8, 8, True), (3, 192, 576, 8, 20, True),
-                                           (2, 192, 1020, 32, 32, False), (9, 192, 510, 16, 16, True)])
+                                           (2, 192, 1020, 32, 32, False), (9, 192, 510, 16, 16, True), (2, 48, 144, 32, 32, True),
+                                           (3, 48, 254, 8, 20, False)])
 def test_input_gradient_fused_with_the_layernorm_backward(b, c, k, h, w, res):
     """pir_conv1x1_dgrad_ln_bwd (C-stationary kernel, LayerNorm backward in the store tail) vs the separate input-gradient
     GEMM + pir_layernorm_bwd, and vs autograd of conv1x1(LayerNorm(x)) on the CPU; idle waves (15 column blocks), several
@@ -222,7 +223,8 @@ def test_input_gradient_fused_with_the_layernorm_backward(b, c, k, h, w, res):
 @pytest.mark.parametrize("b,c,k,h,w,res,dgrad", [(2, 96, 510, 32, 32, False, True), (3, 96, 255, 8, 20, True, False),
                                                  (1, 96, 288, 64, 64, False, True), (5, 96, 288, 8, 8, True, False),
                                                  (3, 192, 510, 8, 20, True, False), (2, 192, 1020, 32, 32, False, True),
-                                                 (9, 192, 576, 16, 16, False, True)])
+                                                 (9, 192, 576, 16, 16, False, True), (2, 48, 127, 32, 32, True, False),
+                                                 (3, 48, 144, 8, 20, False, True), (2, 48, 254, 16, 16, False, True)])
 def test_c_stationary_gemm_equals_the_tiled_kernel(b, c, k, h, w, res, dgrad):
     """gemm_cst.hip (knob 26; 96 or 192 output rows against a long k) against the tiled bf16x3 kernel, bit for bit: residual,
     k tails (255, 510, 1020), idle waves in the last workgroup (15 and 10 column blocks), several rounds."""

@@ -24,7 +24,7 @@ def main():
     B = args.batch
     L = _lib.lib
     shapes = []   # (tag, cout, cin, side, residual, dgrad)
-    for C, S in ((96, 128), (96, 64), (192, 32)):
+    for C, S in ((48, 128), (96, 128), (96, 64), (192, 32)):
         hid = int(C * 2.66)
         shapes += [(f"C{C} {S}^2 ffn_out fwd+R", C, hid, S, True, False), (f"C{C} {S}^2 qkv dgrad", 3 * C, C, S, False, True),
                    (f"C{C} {S}^2 ffn_in dgrad", 2 * hid, C, S, False, True)]

@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     B = ap.parse_args().batch
     print(f"batch {B}\n{'shape':24s} | {'pair us':>9s} {'fused us':>9s} {'ratio':>6s} | fused GB/s (alg.)")
-    for c, S in ((96, 128), (96, 64), (192, 32)):
+    for c, S in ((48, 128), (96, 128), (96, 64), (192, 32)):
         for tag, K in (("qkv (LN1)", 3 * c), ("ffn_in (LN2)", 2 * int(c * 2.66))):
             x, w, dy, dres = r(B, c, S, S), r(K, c, 1, 1), r(B, K, S, S), r(B, c, S, S)
             gam, bet = r(c), r(c)
