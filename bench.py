@@ -6,7 +6,8 @@
 
 One JSON line on rank 0 (contract in the task statement).  `value` is the whole-job patches/s with
 inputs resident in HBM.  `roofline` describes the dominant kernel family (the kernels behind pir_gemm_nn - tiled gemm_nn_x3_kernel and the
-persistent gemm_nn_bst_kernel / gemm_nn_res_kernel: every 1x1 convolution, its input gradient, and attn@v) measured live with HIP events on the launch
+persistent gemm_nn_bst_kernel / gemm_nn_res_kernel / gemm_nn_cst_kernel: every 1x1 convolution, its input gradient where that is not
+fused with a LayerNorm backward (pir_conv1x1_dgrad_ln_bwd is reported as its own family), and attn@v) measured live with HIP events on the launch
 stream in one extra, instrumented step after the timed region.  `cpu_baseline` is the CPU oracle
 (oracle/promptir_ref.py, PyTorch fp32 on the host cores) on a bounded sample of the same workload.
 """
@@ -277,7 +278,7 @@ def main():
             if fam_t:
                 traffic = round((2.0 * fam_t["fetch_kb_per_launch_raw"] + fam_t["write_kb_per_launch"]) * 1024)
                 traffic_note = "profiles/r03_traffic.json: " + tj["source"] + "; " + tj["note"]
-        roofline = {"kernel": ("gemm_nn_x3_kernel + gemm_nn_bst_kernel + gemm_nn_res_kernel" if x3 else "gemm_nn_kernel") +
+        roofline = {"kernel": ("gemm_nn_x3_kernel + gemm_nn_bst_kernel + gemm_nn_res_kernel + gemm_nn_cst_kernel<LNB=false>" if x3 else "gemm_nn_kernel") +
                               " (every kernel behind pir_gemm_nn)",
                     "bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch",

@@ -50,6 +50,9 @@ class _TimedLib:
         if name == "pir_gemm_nt":
             g = args[0]._obj
             return 4.0 * g.O1 * g.O2 * g.BR * (g.M1 + g.M2) * g.N
+        if name == "pir_conv1x1_dgrad_ln_bwd":     # dy read, x and the residual gradient read, dx written, statistics read
+            k, (b, c, hw) = args[4], args[18:21]
+            return 4.0 * b * hw * (k + 3 * c + 2)
         return 0.0
 
     @staticmethod
@@ -61,6 +64,9 @@ class _TimedLib:
         if name == "pir_gemm_nt":
             g = args[0]._obj
             return 2.0 * g.M1 * g.M2 * g.N * g.O1 * g.O2 * g.BR
+        if name == "pir_conv1x1_dgrad_ln_bwd":
+            k, (b, c, hw) = args[4], args[18:21]
+            return 2.0 * c * k * hw * b
         if name == "pir_conv3x3":
             b, m, k, h, w = args[11:16]
             return 2.0 * 9 * m * k * h * w * b

@@ -218,12 +218,15 @@ def test_gemm_plan_reaches_the_tuned_tiles_for_config3_shapes():
     assert plan(255, 96, 4096, 32) == 9100       # project_out input gradient, level 2
     assert plan(288, 96, 16384, 32) == 9000      # qkv forward, dec1 / refinement: resident weight panel, three row tiles
     assert plan(510, 96, 16384, 2) == 2222       # a test-sized batch has too few column blocks per workgroup: 128 x 128 tiles
-    assert plan(96, 510, 16384, 32) == 3114      # project_in input gradient (M = 96, K = 510, N = 16384): 96 x 128
+    assert plan(96, 510, 16384, 32) == 9200      # project_in input gradient (M = 96, K = 510): C-stationary (gemm_cst.hip)
+    assert plan(96, 255, 4096, 32) == 9200       # project_out forward of the GDFN, level 2
+    assert plan(192, 1020, 1024, 32) == 3114     # 192 rows: C-stationary only inside the fused LayerNorm backward
     assert plan(255, 96, 16384, 32) == 2222      # project_out input gradient at 128^2 (A/B: no gain from the persistent kernels)
-    assert plan(96, 510, 16384, 2) == 3114       # the test-sized batch takes the same branch
+    assert plan(96, 510, 16384, 2) == 9200       # the test-sized batch takes the same branch
+    assert plan(96, 96, 16384, 32) == 3214       # short k stays on the tiled kernel (96 x 256)
     assert plan(48, 48, 16384, 32) == 1222
-    assert plan(48, 144, 16384, 32) == 1222      # 64 x 128 up to k = 192 ...
-    assert plan(48, 254, 16384, 32) == 2214      # ... 64 x 256 beyond
+    assert plan(48, 144, 16384, 32) == 9200      # 48 rows against k >= 128: C-stationary, 64-row tiles with zero padding rows
+    assert plan(48, 254, 16384, 32) == 9200
     assert plan(576, 192, 1024, 32) == 3114      # low-resolution levels: 96 x 128 ...
     assert plan(384, 2042, 256, 32) == 3114
     assert plan(1020, 192, 1024, 32) == 2222     # ... unless 128-row tiles pad less

@@ -99,7 +99,10 @@ def is_conv(k):
 fam = {}
 for r in rows:
     k = r["kernel"]
-    if (k.startswith("gemm_nn_x3_kernel") and not is_conv(k)) or k.startswith("gemm_nn_res_kernel") or k.startswith("gemm_nn_bst_kernel"):
+    if k.startswith("gemm_nn_cst_kernel") and template_args(k)[3] == "true":   # <TM, PK, NW, LNB, MR>: LayerNorm backward fused
+        name = "pir_conv1x1_dgrad_ln_bwd"
+    elif (k.startswith("gemm_nn_x3_kernel") and not is_conv(k)) or k.startswith("gemm_nn_res_kernel") or k.startswith("gemm_nn_bst_kernel") \
+            or k.startswith("gemm_nn_cst_kernel"):
         name = "pir_gemm_nn"
     elif k.startswith("gemm_nn_x3_kernel"):
         name = "pir_conv3x3_x3"
