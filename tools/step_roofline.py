@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Per-shape roofline of one instrumented train step: every pir_gemm_nn / pir_gemm_nt call with its
-shape, measured time, and the time its own roofline allows (bf16x3 MFMA ceiling and HBM ceiling)."""
+"""Per-shape roofline of one instrumented train step: every pir_gemm_nn / pir_gemm_nt / pir_conv1x1_dgrad_ln_bwd call
+with its shape, measured time, and the time its own roofline allows (bf16x3 MFMA ceiling and HBM ceiling).  "fl" rows are
+the input gradients fused with a LayerNorm backward (M = C, K = cout; bytes: dy, x, dres read, dx written)."""
 import argparse
 import os
 import sys
@@ -30,7 +31,7 @@ torch.cuda.synchronize()
 
 shapes = []
 raw = ops.lib._raw
-orig_nn, orig_nt = raw.pir_gemm_nn, raw.pir_gemm_nt
+orig_nn, orig_nt, orig_fl = raw.pir_gemm_nn, raw.pir_gemm_nt, raw.pir_conv1x1_dgrad_ln_bwd
 
 
 class Spy:
@@ -38,6 +39,11 @@ class Spy:
         self.fn, self.kind = fn, kind
 
     def __call__(self, *a):
+        if self.kind == "fl":
+            k, (b, c, hw) = a[4], a[18:21]
+            st = self.fn(*a)    # 1000 = shape not served (nothing launched): the pair of calls that follows is recorded
+            shapes.append((("fl" if st != 1000 else "skip", c, k, hw, b, 1, 1, 0), 2.0 * c * k * hw * b, 4.0 * b * hw * (k + 3 * c + 2)))
+            return st
         g = a[0]._obj
         if self.kind == "nn":
             key = ("nn", g.M, g.K, g.N, g.O1 * g.O2, bool(g.R), bool(g.A3), int(g.a_sm == 1))
@@ -52,17 +58,19 @@ class Spy:
         return self.fn(*a)
 
 
-raw.pir_gemm_nn, raw.pir_gemm_nt = Spy(orig_nn, "nn"), Spy(orig_nt, "nt")
+raw.pir_gemm_nn, raw.pir_gemm_nt, raw.pir_conv1x1_dgrad_ln_bwd = Spy(orig_nn, "nn"), Spy(orig_nt, "nt"), Spy(orig_fl, "fl")
 ops.lib.start_timing()
 tr.train_step(x, t)
-recs = [r for r in ops.lib.stop_timing() if r[0] in ("pir_gemm_nn", "pir_gemm_nt")]
-raw.pir_gemm_nn, raw.pir_gemm_nt = orig_nn, orig_nt
+recs = [r for r in ops.lib.stop_timing() if r[0] in ("pir_gemm_nn", "pir_gemm_nt", "pir_conv1x1_dgrad_ln_bwd")]
+raw.pir_gemm_nn, raw.pir_gemm_nt, raw.pir_conv1x1_dgrad_ln_bwd = orig_nn, orig_nt, orig_fl
 assert len(recs) == len(shapes), (len(recs), len(shapes))
 agg = {}
 for (name, sec, _, _), (key, flops, byts) in zip(recs, shapes):
+    if key[0] == "skip":
+        continue
     a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
     a[0] += 1; a[1] += sec; a[2] += flops; a[3] += byts
-tot = {"nn": [0.0, 0.0], "nt": [0.0, 0.0]}
+tot = {"nn": [0.0, 0.0], "nt": [0.0, 0.0], "fl": [0.0, 0.0]}
 print(f"{'kind':3} {'M':>5} {'K':>5} {'N':>6} {'bat':>4} R A3 mf | calls  time_us  bound_us  mfma_us  hbm_us  eff")
 rows = []
 for key, (calls, sec, flops, byts) in agg.items():
