@@ -319,6 +319,7 @@ void gemm_nn_cst_kernel(CstArgs p) {
 }
 
 int g_cst_mode = -1;   // knob 26: -1 automatic, 0 never, 1 whenever the shape is served
+int g_cst_ln_maxc = 192;   // knob 27: most channels the fused LayerNorm backward serves (A/B of the 192-channel variant)
 
 bool cst_plan(const pir_gemm_nn_t& g, CstArgs& a, int& grid, int& pk, bool lnb = false) {
   if (g_cst_mode == 0 && !lnb) return false;
@@ -355,8 +356,7 @@ bool cst_plan(const pir_gemm_nn_t& g, CstArgs& a, int& grid, int& pk, bool lnb =
 }  // namespace
 
 int pir_nn_cst_tune(int knob, int value) {
-  if (knob != 26) return PIR_EINVAL;
-  g_cst_mode = value;
+  if (knob == 26) g_cst_mode = value; else if (knob == 27) g_cst_ln_maxc = value; else return PIR_EINVAL;
   return PIR_OK;
 }
 
@@ -396,6 +396,7 @@ extern "C" int pir_conv1x1_dgrad_ln_bwd(const float* dy, long dy_bs, const void*
   g.rowscale = nullptr; g.rs_s1 = g.rs_s2 = 0;
   g.M = C; g.K = K; g.N = HW; g.O1 = B; g.O2 = 1; g.A3 = A3; g.a3_kp = a3_kp;
   CstArgs a; int grid = 0, pk = 0;
+  if (C > g_cst_ln_maxc) return 1000;
   if (!cst_plan(g, a, grid, pk, true)) return 1000;
   if ((reinterpret_cast<uintptr_t>(x) & 15) || x_bs % 4 || (reinterpret_cast<uintptr_t>(mean) & 15) || (reinterpret_cast<uintptr_t>(rstd) & 15)) return 1000;
   if (dres && ((reinterpret_cast<uintptr_t>(dres) & 15) || dres_bs % 4)) return 1000;
