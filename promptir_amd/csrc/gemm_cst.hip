@@ -221,7 +221,7 @@ void gemm_nn_cst_kernel(CstArgs p) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int G = 0; G < 4; ++G)
-          xv[i][G] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vx + (i * 32 + 8 * G) * n4, 0, 0));
+          xv[i][G] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vx, (i * 32 + 8 * G) * n4, 0));
       f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -246,20 +246,20 @@ void gemm_nn_cst_kernel(CstArgs p) {
       f32x4 rv[2][4];
 #pragma unroll
       for (int G = 0; G < 4; ++G)
-        rv[0][G] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, vx + (8 * G) * n4, 0, 0));
+        rv[0][G] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, vx, (8 * G) * n4, 0));
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         __builtin_amdgcn_sched_barrier(0);
         if (i + 1 < TM) {
 #pragma unroll
           for (int G = 0; G < 4; ++G)
-            rv[(i + 1) & 1][G] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, vx + ((i + 1) * 32 + 8 * G) * n4, 0, 0));
+            rv[(i + 1) & 1][G] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, vx, ((i + 1) * 32 + 8 * G) * n4, 0));
         }
 #pragma unroll
         for (int G = 0; G < 4; ++G) {
           const f32x4 gg = {acc[i][4 * G], acc[i][4 * G + 1], acc[i][4 * G + 2], acc[i][4 * G + 3]};
           const f32x4 v = rs * (gg - m1 - xv[i][G] * m2) + rv[i & 1][G];
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, vy + (i * 32 + 8 * G) * ldy * 4, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, pir_row_offset(vy, (i * 32 + 8 * G) * ldy * 4), 0, 0);
         }
       }
     } else {
@@ -276,7 +276,7 @@ void gemm_nn_cst_kernel(CstArgs p) {
         if (has_r) {
 #pragma unroll
           for (int G = 0; G < 4; ++G)
-            res[G] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, vr + (i * 32 + 8 * G) * ldr * 4, 0, 0));
+            res[G] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, vr, (i * 32 + 8 * G) * ldr * 4, 0));
         }
 #pragma unroll
         for (int G = 0; G < 4; ++G) {
@@ -284,7 +284,7 @@ void gemm_nn_cst_kernel(CstArgs p) {
           res_transpose4(a0, a1, a2, a3);
           f32x4 v = {a0, a1, a2, a3};
           if (has_r) v += res[G];
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, vy + (i * 32 + 8 * G) * ldy * 4, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, pir_row_offset(vy, (i * 32 + 8 * G) * ldy * 4), 0, 0);
         }
       }
     }

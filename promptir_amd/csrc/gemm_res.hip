@@ -248,7 +248,7 @@ void gemm_nn_res_kernel(ResArgs p) {
         if (has_r) {
 #pragma unroll
           for (int G = 0; G < 4; ++G)
-            res[G] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, vr + (i * 32 + 8 * G) * ldr * 4, 0, 0));
+            res[G] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, vr, (i * 32 + 8 * G) * ldr * 4, 0));
         }
 #pragma unroll
         for (int G = 0; G < 4; ++G) {
@@ -256,7 +256,7 @@ void gemm_nn_res_kernel(ResArgs p) {
           res_transpose4(a0, a1, a2, a3);
           f32x4 v = {a0, a1, a2, a3};
           if (has_r) v += res[G];
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, vy + (i * 32 + 8 * G) * ldy * 4, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, pir_row_offset(vy, (i * 32 + 8 * G) * ldy * 4), 0, 0);
         }
       }
     }
@@ -291,7 +291,7 @@ template <int KS, int NT, int TP, bool LN = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
 void gemm_nn_bst_kernel(BstArgs p) {
   constexpr int NW = 8, T = 512, BP = 32 * TP, KG = 2 * KS, PART = KG * BP, PANEL = 3 * PART;
-  constexpr int NLD = (PANEL + T - 1) / T;    // 16-byte units per thread and panel
+  constexpr int NLD = (3 * KS + 1) / 2;       // passes (16-byte units per thread) per panel: two (part, k-step) slices each
   __shared__ bf16x8 smem[2 * PANEL];
   __shared__ f32x4 lnp[LN ? 2 * KS * 4 : 1];  // gamma then beta, K floats each
   const pir_gemm_nn_t& g = p.g;
@@ -307,30 +307,25 @@ void gemm_nn_bst_kernel(BstArgs p) {
   const __amdgpu_buffer_rsrc_t ars = pir_make_rsrc(g.A3, (unsigned)(6L * g.M * g.a3_kp));
   const int part_bytes = g.M * g.a3_kp * 2;
 
-  // ---- weight panel `pi` (rows 128 pi ..): 16-byte unit (pass idx, thread) -> registers -> LDS buffer `buf`.
-  // Unit u = tid + 512 idx is (kg = u & 1, row = (u >> 1) % 128, c = (u >> 8) = part * KS + ks): row and kg depend on
-  // the lane only, c on the pass and on the workgroup half (waves 0-3 / 4-7) only - scalar arithmetic, two VGPRs.
+  // ---- weight panel `pi` (rows BP pi ..): 16-byte unit (pass idx, thread) -> registers -> LDS buffer `buf`.
+  // A pass covers two (part, k-step) slices c of the panel: thread t holds (kg = t & 1, row = (t >> 1) % BP) for all
+  // passes and c = 2 idx + (t >> 1) / BP, which is uniform over a wave (BP = 128: waves 0-3 / 4-7; BP = 96: waves 0-2 /
+  // 3-5, waves 6-7 stay out of the panel traffic) - scalar arithmetic and two VGPRs instead of per-pass address registers.
   const int p_kg = tid & 1, p_row = (tid >> 1) % BP;
-  // c = (u >> 1) / BP: BP = 128 makes it pass- and workgroup-half-uniform (scalar); BP = 96 needs the per-lane quotient
-  const int p_c0 = (tid >> 1) / BP;
+  const int p_c0 = __builtin_amdgcn_readfirstlane((tid >> 1) / BP);
+  const bool p_on = p_c0 < 2;
   auto panel_load = [&](int pi, int idx) {
-    const int c0 = BP == 128 ? __builtin_amdgcn_readfirstlane(p_c0) + 2 * idx : (tid + idx * T) / (2 * BP);
-    const int c = c0 < 3 * KS ? c0 : 0;                              // (a last pass may be partly empty)
+    const int c0 = p_c0 + 2 * idx;
+    const int c = (p_on && c0 < 3 * KS) ? c0 : 0;                    // (a last pass may be partly empty)
     const int ks = c % KS, part = c / KS;
-    const int row = BP == 128 ? p_row : ((tid + idx * T) >> 1) % BP;
-    const int m = pi * BP + row, mc = m < g.M ? m : g.M - 1;         // rows beyond M only feed dropped outputs
-    if constexpr (BP == 128)   // (part, k-step) uniform: scalar offset (rows are clamped, nothing relies on the range check)
-      return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-          ars, mc * 32 + p_kg * 16, part * part_bytes + ks * g.M * 32, 0));
-    else
-      return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-          ars, mc * 32 + p_kg * 16 + part * part_bytes + ks * g.M * 32, 0, 0));
+    const int m = pi * BP + p_row, mc = m < g.M ? m : g.M - 1;       // rows beyond M only feed dropped outputs
+    // (part, k-step) uniform: scalar offset (rows are clamped, nothing relies on the range check)
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+        ars, mc * 32 + p_kg * 16, part * part_bytes + ks * g.M * 32, 0));
   };
   auto panel_store = [&](int buf, int idx, const bf16x8& v) {
-    const int u = tid + idx * T;
-    const int c = BP == 128 ? __builtin_amdgcn_readfirstlane(p_c0) + 2 * idx : u / (2 * BP);
-    const int row = BP == 128 ? p_row : (u >> 1) % BP;
-    if (PANEL % T == 0 || c < 3 * KS) smem[buf * PANEL + c * 2 * BP + p_kg * BP + row] = v;
+    const int c = p_c0 + 2 * idx;
+    if (p_on && c < 3 * KS) smem[buf * PANEL + c * 2 * BP + p_kg * BP + p_row] = v;
   };
 
   // ---- activations of a column block: 2 x 16-byte loads per k-step (see gemm_nn_res_kernel)
@@ -349,7 +344,7 @@ void gemm_nn_bst_kernel(BstArgs p) {
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
-        raw[ks][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(c.rs, c.vo + (ks * 16 + 4 * t) * ldx4, 0, 0));
+        raw[ks][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(c.rs, c.vo, (ks * 16 + 4 * t) * ldx4, 0));   // row term scalar
   };
 
   // first panel and first block
@@ -392,12 +387,15 @@ void gemm_nn_bst_kernel(BstArgs p) {
         for (int e = 0; e < 8; ++e) { val[ks][e] -= mu; s2 += val[ks][e] * val[ks][e]; }
       s2 += __shfl_xor(s2, 32, 64);
       const float rstd = 1.f / sqrtf(s2 / (float)(16 * KS) + 1e-5f);   // biased variance, eps inside the root (:62-63)
+      const f32x4* lp = lnp + 2 * h + (round >> 30);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         float v[8];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const f32x4 gm = lnp[(16 * ks + 8 * h + 4 * t) >> 2], bt = lnp[4 * KS + ((16 * ks + 8 * h + 4 * t) >> 2)];
+          // one base register + immediate offsets (separately computed addresses were hoisted out of the round loop as
+          // 24 registers and spilled; the reloads in front of every read serialised the round start)
+          const f32x4 gm = lp[4 * ks + t], bt = lp[4 * KS + 4 * ks + t];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[4 * t + e] = val[ks][4 * t + e] * rstd * gm[e] + bt[e];
         }
@@ -488,7 +486,7 @@ void gemm_nn_bst_kernel(BstArgs p) {
               float a0 = acc[e][4 * G], a1 = acc[e][4 * G + 1], a2 = acc[e][4 * G + 2], a3 = acc[e][4 * G + 3];
               res_transpose4(a0, a1, a2, a3);
               f32x4 v = {a0, a1, a2, a3};
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, vy + (mrow + 8 * G) * ldy * 4, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, pir_row_offset(vy, (mrow + 8 * G) * ldy * 4), 0, 0);
             }
           }
         }

@@ -22,3 +22,12 @@ __device__ __forceinline__ void res_transpose4(float& v0, float& v1, float& v2, 
   res_exchange<3>(v0, v2); res_exchange<3>(v1, v3);
 }
 
+
+// per-lane byte offset + wave-uniform row term for a buffer STORE, added at the point of use.  (Written as plain
+// arithmetic the compiler precomputes one offset register per store of a tile - 12 to 16 loop-invariant registers that
+// spill in the persistent kernels; a scalar offset operand, which does this for loads, gave wrong results on stores.)
+__device__ __forceinline__ int pir_row_offset(int lane_off, int row_off) {
+  int r;
+  asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "s"(row_off), "v"(lane_off));
+  return r;
+}

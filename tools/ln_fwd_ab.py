@@ -18,11 +18,15 @@ from tools.resident_ab import r, timeit  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
-    B = ap.parse_args().batch
+    ap.add_argument("--only", type=str, default="")
+    args = ap.parse_args()
+    B = args.batch
     print(f"batch {B}\n{'shape':28s} | {'pair us':>9s} {'fused us':>9s} {'ratio':>6s}")
     for c, S in ((48, 128), (96, 128), (96, 64)):
         hid = int(c * 2.66)
         for tag, M in (("qkv (LN1)", 3 * c), ("ffn_in (LN2)", 2 * hid)):
+            if args.only and args.only not in f"C{c} {S}^2 {tag}":
+                continue
             x, w, gam, bet = r(B, c, S, S), r(M, c, 1, 1), r(c), r(c)
 
             def pair():
