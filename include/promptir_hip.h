@@ -77,9 +77,18 @@ int pir_gemm_nn(const pir_gemm_nn_t* args, pir_stream_t stream);
  * applied as the activations are loaded by the persistent B-stationary kernel, so the normalised tensor of
  * `self.attn(self.norm1(x))` / `self.ffn(self.norm2(x))` (:192-196) is never written or read.  A3 = pir_split_bf16x3 of
  * W [M][K].  Served for K = 48 or 96 channels, HW % 32 == 0, 16-byte aligned planes and enough pixels to fill the
- * chip; returns 1000 (nothing launched) otherwise and the caller runs pir_layernorm_fwd + pir_gemm_nn. */
+ * chip; returns 1000 (nothing launched) otherwise and the caller runs pir_layernorm_fwd + pir_gemm_nn.  Used by the
+ * no_grad forward and, with the statistics written out, by the training forward of the 128^2 levels. */
 int pir_ln_conv1x1_fwd(const float* x, long x_bs, const float* ln_w, const float* ln_b, const void* A3, int a3_kp,
-                       float* y, long y_bs, int B, int M, int K, int HW, pir_stream_t stream);
+                       float* y, long y_bs, float* mean_out, float* rstd_out, int B, int M, int K, int HW, pir_stream_t stream);
+/* Weight gradient of that convolution without the normalised tensor in memory (training): dw[co][ci] = sum_{b,p}
+ * dy[b][co][p] * LayerNorm(x[b])[ci][p], the LayerNorm applied from (mean, rstd, ln_w, ln_b) as gemm_nt_xp_kernel stages
+ * its shared operand.  mean_out / rstd_out of pir_ln_conv1x1_fwd (both or neither; [B][HW]) are the statistics this and
+ * pir_conv1x1_dgrad_ln_bwd read.  Returns 1000 (nothing launched) where the tall-operand-private kernel does not serve the
+ * shape: the caller then materialises LayerNorm(x) (pir_layernorm_fwd) and calls pir_gemm_nt. */
+int pir_conv1x1_wgrad_ln(const float* dy, long dy_bs, const float* x, long x_bs, const float* mean, const float* rstd,
+                         const float* ln_w, const float* ln_b, float* dw, float* ws, size_t ws_floats,
+                         int B, int Cout, int Cin, int HW, pir_stream_t stream);
 
 /* Input gradient of a 1x1 convolution that follows a WithBias channel LayerNorm, fused with that LayerNorm's backward
  * (round 3): dx[b] = LN'(W^T dy[b] | x[b], mean, rstd, ln_w) + dres[b], dweight, dbias of the LayerNorm

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PIR_LIB", os.path.join(_HERE, "libpromptir_hip.so"))  # PIR_LIB: A/B builds in tools/
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_float_p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 c_long = C.c_long
@@ -107,7 +107,8 @@ SIGNATURES = {
     "pir_gelu_gate": (I, [P, L, P, L, I, I, I, S]),
     "pir_gelu_gate_bwd": (I, [P, L, P, L, P, L, I, I, I, S]),
     "pir_reduce_partials": (I, [P, L, I, F, I, P, L, S]),
-    "pir_ln_conv1x1_fwd": (I, [P, L, P, P, P, I, P, L, I, I, I, I, S]),
+    "pir_ln_conv1x1_fwd": (I, [P, L, P, P, P, I, P, L, P, P, I, I, I, I, S]),
+    "pir_conv1x1_wgrad_ln": (I, [P, L, P, L, P, P, P, P, P, P, Z, I, I, I, I, S]),
     "pir_conv1x1_dgrad_ln_bwd": (I, [P, L, P, I, I, P, L, P, P, P, P, L, P, L, P, P, P, Z, I, I, I, S]),
     "pir_mdta_dqk": (I, [P, P, L, L, P, P, P, L, L, I, I, I, I, S]),
     "pir_adamw_step": (I, [P, P, P, P, L, F, F, F, F, F, L, F, S]),

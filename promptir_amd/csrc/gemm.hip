@@ -939,6 +939,20 @@ int launch_nt(NTParams& p, size_t ws_floats, int tap_sign, long g_st, hipStream_
 
 }  // namespace
 
+// second stage of a split-K product whose partials another kernel wrote (gemm_ntx.hip)
+int pir_nt_reduce_launch(const float* ws, int splits, int M1, int M2, float* G, long g_so, long g_si, long g_sj, float alpha,
+                         int accumulate, hipStream_t s) {
+  const long per_split = (long)M1 * M2;
+  const unsigned blocks = (unsigned)pir_cdiv(per_split, 64);
+  if (splits >= 64)
+    hipLaunchKernelGGL((nt_reduce_kernel<16>), dim3(blocks), dim3(1024), 0, s, ws, splits, per_split, M1, M2, G, g_so, g_si, g_sj,
+                       alpha, accumulate, 0L);
+  else
+    hipLaunchKernelGGL((nt_reduce_kernel<4>), dim3(blocks), dim3(256), 0, s, ws, splits, per_split, M1, M2, G, g_so, g_si, g_sj,
+                       alpha, accumulate, 0L);
+  return pir_launch_status();
+}
+
 int pir_gdfn_wave_tune(int knob, int value);   // gdfn_bwd.hip
 int pir_stencil_wave_tune(int knob, int value);   // stencil_wave.hip
 int pir_ln_tune(int knob, int value);             // norm.hip

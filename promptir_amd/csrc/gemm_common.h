@@ -125,6 +125,7 @@ int pir_nn_cst_launch(const pir_gemm_nn_t* a, hipStream_t stream);
 int pir_nn_cst_tune(int knob, int value);
 
 // tall x small weight gradients with the tall operand private to its wave (gemm_ntx.hip): 1000 = shape not served
-int pir_nt_xp_launch(const pir_gemm_nt_t* a, int* splits, hipStream_t stream);
+int pir_nt_xp_launch(const pir_gemm_nt_t* a, int* splits, hipStream_t stream, const float* y_mean = nullptr, const float* y_rstd = nullptr,
+                     const float* y_gamma = nullptr, const float* y_beta = nullptr);   // y_*: LayerNorm applied to Y as it is staged
 int pir_nt_xp_splits(const pir_gemm_nt_t* a);
 int pir_nt_xp_tune(int knob, int value);

@@ -44,11 +44,15 @@ struct XpArgs {
   int splits;        // workgroups = split-K slices
   int steps_per_r;   // N / 32
   int rowblocks;     // ceil(M1 / 32)
+  // YLN: the shared operand is normalised as it is staged - Y <- (Y - mean[pixel]) rstd[pixel] gamma[row] + beta[row], the
+  // WithBias channel LayerNorm (net/model.py:60-63) of the convolution's input, which then never has to be materialised
+  const float* y_mean; const float* y_rstd;   // [BR][N]
+  const float* y_gamma; const float* y_beta;  // [M2]
 };
 
 // RBW: 32-row blocks of X per wave; TN: 32-column blocks of the output (ceil(M2 / 32)); the number of waves is the
 // launch's (rowblocks / RBW rounded up)
-template <int RBW, int TN>
+template <int RBW, int TN, bool YLN = false>
 __global__ __launch_bounds__(RBW == 2 ? 512 : 576) __attribute__((amdgpu_waves_per_eu(2)))
 void gemm_nt_xp_kernel(XpArgs p) {
   constexpr int YR = TN * 32;             // rows of the shared operand held per stage (padded)
@@ -78,11 +82,25 @@ void gemm_nt_xp_kernel(XpArgs p) {
   const int yoff = (yj < g.M2 ? yj : g.M2 - 1) * (int)g.ldy + 8 * yq;
   const int ydst = ((yq & 1) * 2 + (yq >> 1)) * YR + yj;             // unit (m, h', row) inside a part
 
+  long stat_off = 0;                                                  // YLN: offset of the step's pixels in mean / rstd
   auto base = [&](int s, const float*& xp, const float*& yp) {       // image and pixel of flattened step s
     const int sc = s < total ? s : total - 1;
     const int img = sc / p.steps_per_r, st = sc - img * p.steps_per_r;
     xp = g.X + (long)img * g.x_sr + st * 32;
     yp = g.Y + (long)img * g.y_sr + st * 32;
+    if constexpr (YLN) stat_off = (long)img * g.N + st * 32 + 8 * yq;
+  };
+  const float y_gam = YLN ? p.y_gamma[yj < g.M2 ? yj : g.M2 - 1] : 1.f, y_bet = YLN ? p.y_beta[yj < g.M2 ? yj : g.M2 - 1] : 0.f;
+  f32x4 ym[2], ys[2];
+  auto load_stats = [&]() {
+    if constexpr (YLN) {
+      ym[0] = *reinterpret_cast<const f32x4*>(p.y_mean + stat_off); ym[1] = *reinterpret_cast<const f32x4*>(p.y_mean + stat_off + 4);
+      ys[0] = *reinterpret_cast<const f32x4*>(p.y_rstd + stat_off); ys[1] = *reinterpret_cast<const f32x4*>(p.y_rstd + stat_off + 4);
+    }
+  };
+  auto ysplit = [&](const f32x4& a, const f32x4& b) {
+    if constexpr (YLN) return xp_split8((a - ym[0]) * ys[0] * y_gam + y_bet, (b - ym[1]) * ys[1] * y_gam + y_bet);
+    else return xp_split8(a, b);
   };
 
   f32x4 xr[RBW][4];                 // raw X of the current step, refilled half by half for the next one
@@ -96,9 +114,10 @@ void gemm_nt_xp_kernel(XpArgs p) {
   __builtin_amdgcn_sched_barrier(0);
   yr[0] = *reinterpret_cast<const f32x4*>(yp + yoff);
   yr[1] = *reinterpret_cast<const f32x4*>(yp + yoff + 4);
+  load_stats();
   __builtin_amdgcn_sched_barrier(0);
   {
-    const XFrag3 f = xp_split8(yr[0], yr[1]);
+    const XFrag3 f = ysplit(yr[0], yr[1]);
     if (yact) { smem[ydst] = f.hi; smem[YU + ydst] = f.mid; smem[2 * YU + ydst] = f.lo; }
   }
   __syncthreads();
@@ -128,6 +147,7 @@ void gemm_nt_xp_kernel(XpArgs p) {
         if (m == 0) {
           yr[0] = *reinterpret_cast<const f32x4*>(yn + yoff);
           yr[1] = *reinterpret_cast<const f32x4*>(yn + yoff + 4);
+          load_stats();
         }
 #pragma unroll
         for (int c = 0; c < TN; ++c) {
@@ -137,7 +157,7 @@ void gemm_nt_xp_kernel(XpArgs p) {
       }
       __builtin_amdgcn_sched_barrier(0);
       {   // the next step's slice of the shared operand into the other buffer
-        const XFrag3 f = xp_split8(yr[0], yr[1]);
+        const XFrag3 f = ysplit(yr[0], yr[1]);
         bf16x8* dst = smem + (buf ^ 1) * STAGE;
         if (yact) { dst[ydst] = f.hi; dst[YU + ydst] = f.mid; dst[2 * YU + ydst] = f.lo; }
       }
@@ -169,6 +189,7 @@ void gemm_nt_xp_kernel(XpArgs p) {
         if (m == 0 && e == 0) {
           yr[0] = *reinterpret_cast<const f32x4*>(yn + yoff);
           yr[1] = *reinterpret_cast<const f32x4*>(yn + yoff + 4);
+          load_stats();
         }
         // next unit: (m, e + 1), (m + 1, 0) or the next step's (0, 0) - whose registers were refilled a step ago
         constexpr int dummy = 0; (void)dummy;
@@ -188,7 +209,7 @@ void gemm_nt_xp_kernel(XpArgs p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     {   // the next step's slice of the shared operand into the other buffer
-      const XFrag3 f = xp_split8(yr[0], yr[1]);
+      const XFrag3 f = ysplit(yr[0], yr[1]);
       bf16x8* dst = smem + (buf ^ 1) * STAGE;
       if (yact) { dst[ydst] = f.hi; dst[YU + ydst] = f.mid; dst[2 * YU + ydst] = f.lo; }
     }
@@ -258,20 +279,55 @@ int pir_nt_xp_splits(const pir_gemm_nt_t* a) {
 }
 
 // Launches the split-K kernel only (partials into g.ws, `*splits` slices); the caller runs the reduction.  1000: not served.
-int pir_nt_xp_launch(const pir_gemm_nt_t* a, int* splits, hipStream_t s) {
+int pir_nt_xp_launch(const pir_gemm_nt_t* a, int* splits, hipStream_t s, const float* y_mean, const float* y_rstd,
+                     const float* y_gamma, const float* y_beta) {
   XpPlan pl;
   if (!xp_plan(*a, pl)) return 1000;
   if ((size_t)pl.splits * a->M1 * a->M2 > a->ws_floats) return 1000;
   XpArgs xa;
   xa.g = *a;
+  xa.y_mean = y_mean; xa.y_rstd = y_rstd; xa.y_gamma = y_gamma; xa.y_beta = y_beta;
   xa.splits = pl.splits;
   xa.steps_per_r = a->N / 32;
   xa.rowblocks = pl.rowblocks;
   const dim3 grid((unsigned)pl.splits), block((unsigned)pl.nwv * 64);
+  if (y_mean) {
+    if (pl.rbw == 2 && pl.tn == 3) hipLaunchKernelGGL((gemm_nt_xp_kernel<2, 3, true>), grid, block, 0, s, xa);
+    else if (pl.rbw == 2) hipLaunchKernelGGL((gemm_nt_xp_kernel<2, 2, true>), grid, block, 0, s, xa);
+    else if (pl.tn == 3) hipLaunchKernelGGL((gemm_nt_xp_kernel<1, 3, true>), grid, block, 0, s, xa);
+    else hipLaunchKernelGGL((gemm_nt_xp_kernel<1, 2, true>), grid, block, 0, s, xa);
+    *splits = pl.splits;
+    return pir_launch_status();
+  }
   if (pl.rbw == 2 && pl.tn == 3) hipLaunchKernelGGL((gemm_nt_xp_kernel<2, 3>), grid, block, 0, s, xa);
   else if (pl.rbw == 2) hipLaunchKernelGGL((gemm_nt_xp_kernel<2, 2>), grid, block, 0, s, xa);
   else if (pl.tn == 3) hipLaunchKernelGGL((gemm_nt_xp_kernel<1, 3>), grid, block, 0, s, xa);
   else hipLaunchKernelGGL((gemm_nt_xp_kernel<1, 2>), grid, block, 0, s, xa);
   *splits = pl.splits;
   return pir_launch_status();
+}
+
+int pir_nt_reduce_launch(const float* ws, int splits, int M1, int M2, float* G, long g_so, long g_si, long g_sj, float alpha,
+                         int accumulate, hipStream_t s);   // gemm.hip: the deterministic second stage of the split-K products
+
+// dW[co][ci] = sum_{b,p} dy[b][co][p] * LayerNorm(x[b])[ci][p] with the normalisation applied as x is staged: the weight
+// gradient of a 1x1 convolution whose input was the WithBias LayerNorm of x (net/model.py:60-63, 192-196) without that
+// input in memory.  1000 = shape not served (nothing launched; the caller materialises LayerNorm(x) and calls pir_gemm_nt).
+extern "C" int pir_conv1x1_wgrad_ln(const float* dy, long dy_bs, const float* x, long x_bs, const float* mean, const float* rstd,
+                                    const float* ln_w, const float* ln_b, float* dw, float* ws, size_t ws_floats,
+                                    int B, int Cout, int Cin, int HW, pir_stream_t stream) {
+  PIR_CHECK_ARG(dy && x && mean && rstd && ln_w && ln_b && dw && ws && B > 0 && Cout > 0 && Cin > 0 && HW > 0);
+  if (Cout < Cin) return 1000;                       // the normalised operand must be the small (shared) one
+  if ((reinterpret_cast<uintptr_t>(mean) & 15) || (reinterpret_cast<uintptr_t>(rstd) & 15)) return 1000;
+  pir_gemm_nt_t g;
+  g.X = dy; g.x_s1 = g.x_s2 = 0; g.x_sr = dy_bs; g.ldx = HW;
+  g.Y = x; g.y_s1 = g.y_s2 = 0; g.y_sr = x_bs; g.ldy = HW;
+  g.G = dw; g.g_so = 0; g.g_si = Cin; g.g_sj = 1;
+  g.M1 = Cout; g.M2 = Cin; g.N = HW; g.O1 = 1; g.O2 = 1; g.BR = B;
+  g.shift_dh = g.shift_dw = 0; g.H = 0; g.W = 0;
+  g.ws = ws; g.ws_floats = ws_floats; g.alpha = 1.f; g.accumulate = 0;
+  int splits = 0;
+  const int st = pir_nt_xp_launch(&g, &splits, (hipStream_t)stream, mean, rstd, ln_w, ln_b);
+  if (st) return st;
+  return pir_nt_reduce_launch(ws, splits, Cout, Cin, dw, 0, Cin, 1, 1.f, 0, (hipStream_t)stream);
 }

@@ -280,6 +280,7 @@ struct BstArgs {
   int per_wg;     // column blocks per workgroup (a multiple of 8: one per wave and round)
   int panels;     // ceil(M / panel height)
   const float* ln_w; const float* ln_b;   // LN variant: gamma, beta [K] of the channel LayerNorm applied on load
+  float* mean_out; float* rstd_out;       // LN variant: the statistics [O1][N] for the backward pass (or null)
 };
 
 // NT: 32-row output tiles multiplied at a time (2 where registers allow: K = 48); TP: tiles per weight panel (3 or 4:
@@ -387,6 +388,11 @@ void gemm_nn_bst_kernel(BstArgs p) {
         for (int e = 0; e < 8; ++e) { val[ks][e] -= mu; s2 += val[ks][e] * val[ks][e]; }
       s2 += __shfl_xor(s2, 32, 64);
       const float rstd = 1.f / sqrtf(s2 / (float)(16 * KS) + 1e-5f);   // biased variance, eps inside the root (:62-63)
+      if (p.mean_out && active && h == 0) {                            // lane r stands for pixel 4 qk + qj of the block
+        const int so = pir_fastdiv(my, p.magic_nbpi);
+        const long at = (long)so * g.N + (my - so * p.nbpi) * 32 + 4 * qk + qj;
+        p.mean_out[at] = mu; p.rstd_out[at] = rstd;
+      }
       const f32x4* lp = lnp + 2 * h + (round >> 30);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -632,12 +638,13 @@ static bool bst_plan(const pir_gemm_nn_t& g, BstArgs& a, int& grid, bool ln = fa
   return true;
 }
 
-int pir_nn_bst_launch(const pir_gemm_nn_t* g, hipStream_t s, const float* ln_w = nullptr, const float* ln_b = nullptr) {
+int pir_nn_bst_launch(const pir_gemm_nn_t* g, hipStream_t s, const float* ln_w = nullptr, const float* ln_b = nullptr,
+                      float* mean_out = nullptr, float* rstd_out = nullptr) {
   BstArgs a;
   int grid = 0;
   const bool ln = ln_w != nullptr;
   if (!bst_plan(*g, a, grid, ln)) return 1000;
-  a.ln_w = ln_w; a.ln_b = ln_b;
+  a.ln_w = ln_w; a.ln_b = ln_b; a.mean_out = mean_out; a.rstd_out = rstd_out;
   if (ln) {
     const bool q96 = (long)a.panels * 96 >= g->M && (long)a.panels * 96 < pir_cdiv(g->M, 128) * 128 && g->a3_kp == 96;
     if (g->a3_kp == 96 && q96) hipLaunchKernelGGL((gemm_nn_bst_kernel<6, 1, 3, true>), dim3((unsigned)grid), dim3(512), 0, s, a);
@@ -663,8 +670,9 @@ int pir_nn_res_kind(const pir_gemm_nn_t* a) {
 
 // y = W LayerNorm(x) for the no_grad forward: 1000 = shape not served (nothing launched)
 extern "C" int pir_ln_conv1x1_fwd(const float* x, long x_bs, const float* ln_w, const float* ln_b, const void* A3, int a3_kp,
-                                  float* y, long y_bs, int B, int M, int K, int HW, pir_stream_t stream) {
-  PIR_CHECK_ARG(x && ln_w && ln_b && A3 && y && B > 0 && M > 0 && K > 0 && HW > 0);
+                                  float* y, long y_bs, float* mean_out, float* rstd_out, int B, int M, int K, int HW,
+                                  pir_stream_t stream) {
+  PIR_CHECK_ARG(x && ln_w && ln_b && A3 && y && B > 0 && M > 0 && K > 0 && HW > 0 && (mean_out == nullptr) == (rstd_out == nullptr));
   pir_gemm_nn_t g;
   g.A = nullptr; g.a_s1 = g.a_s2 = 0; g.a_sm = K; g.a_sk = 1;
   g.X = x; g.x_s1 = x_bs; g.x_s2 = 0; g.ldx = HW;
@@ -672,7 +680,7 @@ extern "C" int pir_ln_conv1x1_fwd(const float* x, long x_bs, const float* ln_w, 
   g.R = nullptr; g.r_s1 = g.r_s2 = 0; g.ldr = 0;
   g.rowscale = nullptr; g.rs_s1 = g.rs_s2 = 0;
   g.M = M; g.K = K; g.N = HW; g.O1 = B; g.O2 = 1; g.A3 = A3; g.a3_kp = a3_kp;
-  return pir_nn_bst_launch(&g, (hipStream_t)stream, ln_w, ln_b);
+  return pir_nn_bst_launch(&g, (hipStream_t)stream, ln_w, ln_b, mean_out, rstd_out);
 }
 
 int pir_nn_res_launch(const pir_gemm_nn_t* a, hipStream_t s) {

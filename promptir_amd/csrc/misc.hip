@@ -184,7 +184,7 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 }  // namespace
 
-extern "C" int pir_abi_version(void) { return 6; }
+extern "C" int pir_abi_version(void) { return 7; }
 extern "C" const char* pir_arch(void) { return "gfx950"; }
 
 extern "C" int pir_l1_loss(const float* restored, const float* clean, float* loss, float* grad, float gscale,

@@ -339,10 +339,11 @@ def conv1x1_forward(x: torch.Tensor, w: torch.Tensor, residual: Optional[torch.T
     return out
 
 
-def ln_conv1x1_forward(x: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, w: torch.Tensor) -> Optional[torch.Tensor]:
+def ln_conv1x1_forward(x: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, w: torch.Tensor, stats: bool = False):
     """y[b] = W LayerNorm_c(x[b]) with the channel LayerNorm applied on load (pir_ln_conv1x1_fwd): the normalised tensor
-    is never written.  For the no_grad forward (nothing needs it afterwards).  None when the kernel does not serve the
-    shape - the caller then runs layernorm_forward + conv1x1_forward."""
+    is never written.  no_grad forward: nothing needs it afterwards; training (`stats`: returns (y, mean, rstd)): the weight
+    gradient normalises x on load again (conv1x1_wgrad_ln) and the LayerNorm backward reads x and the statistics.  None when
+    the kernel does not serve the shape - the caller then runs layernorm_forward + conv1x1_forward."""
     if not USE_X3 or ln_b is None:
         return None
     x = _planes(x)
@@ -350,12 +351,32 @@ def ln_conv1x1_forward(x: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, 
     cout = w.shape[0]
     a3, kp = _split_weight(w, dgrad=False)
     y = torch.empty((b, cout, h, wd), dtype=torch.float32, device=x.device)
+    mean = torch.empty((b, h * wd), dtype=torch.float32, device=x.device) if stats else None
+    rstd = torch.empty_like(mean) if stats else None
     st = lib.pir_ln_conv1x1_fwd(x.data_ptr(), _bs(x), ln_w.data_ptr(), ln_b.data_ptr(), a3.data_ptr(), kp, y.data_ptr(),
-                                _bs(y), b, cout, cin, h * wd, _stream())
+                                _bs(y), _p(mean), _p(rstd), b, cout, cin, h * wd, _stream())
     if st == 1000:
         return None
     check(st, "pir_ln_conv1x1_fwd")
-    return y
+    return (y, mean, rstd) if stats else y
+
+
+def conv1x1_wgrad_ln(dy, x, mean, rstd, ln_w, ln_b, like, out=None):
+    """dW = sum_b dy[b] LayerNorm(x[b])^T with the LayerNorm applied as the kernel stages x (pir_conv1x1_wgrad_ln); where
+    that kernel does not serve the shape the normalised tensor is materialised first."""
+    dy, x = _planes(dy), _planes(x)
+    b, cout, h, wd = dy.shape
+    cin = x.shape[1]
+    dw = _grad_out(like, out)
+    ws = workspace(lib.pir_gemm_nt_ws_floats(cout, cin, h * wd, 1, b), x.device)
+    st = lib.pir_conv1x1_wgrad_ln(dy.data_ptr(), _bs(dy), x.data_ptr(), _bs(x), mean.data_ptr(), rstd.data_ptr(),
+                                  ln_w.data_ptr(), ln_b.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(),
+                                  b, cout, cin, h * wd, _stream())
+    if st == 1000:
+        xn, _, _ = layernorm_forward(x, ln_w, ln_b)
+        return conv1x1_wgrad(dy, xn, like, dw)
+    check(st, "pir_conv1x1_wgrad_ln")
+    return dw
 
 
 def conv1x1_dgrad(dy: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -919,6 +940,7 @@ class MdtaCoreFn(torch.autograd.Function):
 USE_SIDE_STREAM = _os.environ.get("PIR_SIDE_STREAM", "1") != "0"   # default for callers outside a trainer
 MDTA_FOLD = _os.environ.get("PIR_MDTA_FOLD", "1") != "0"             # fold attn @ v into project_out (TransformerBlockFn)
 LN_FOLD = _os.environ.get("PIR_LN_FOLD", "1") != "0"                 # LayerNorm applied on load in the no_grad forward
+LN_TRAIN = _os.environ.get("PIR_LN_TRAIN", "1") != "0"               # training forward: LayerNorm on load, statistics out, xn never written
 DGRAD_LN = _os.environ.get("PIR_DGRAD_LN", "1") != "0"               # input gradient + LayerNorm backward in one kernel (gemm_cst.hip)
 MDTA_DQK = _os.environ.get("PIR_MDTA_DQK", "1") != "0"               # dq and dk from one pass over q and k (mdta_dqk.hip)
 MDTA_FOLD_MIN_HW = int(_os.environ.get("PIR_MDTA_FOLD_MIN_HW", "4096"))   # ... at the 64^2 / 128^2 levels (below, the
@@ -963,17 +985,20 @@ class _SideWgrads:
                 self.side = _SIDE_STREAMS[key] = torch.cuda.Stream(device)
         self.used = False
 
-    def wgrad(self, dy, x, like, sink):
+    def wgrad(self, dy, x, like, sink, ln=None):
+        """`ln` = (mean, rstd, weight, bias): x is the INPUT of the LayerNorm in front of the convolution (the normalised
+        tensor was never written: ops.ln_conv1x1_forward) and is normalised as the kernel stages it."""
         dw = _grad_out(like, sink)
+        run = (lambda: conv1x1_wgrad(dy, x, like, dw)) if ln is None else (lambda: conv1x1_wgrad_ln(dy, x, *ln, like, dw))
         if self.side is None:
-            return conv1x1_wgrad(dy, x, like, dw)
+            return run()
         ev = torch.cuda.Event()
         ev.record(self.main)
         self.side.wait_event(ev)
         dy.record_stream(self.side)
         x.record_stream(self.side)
         with torch.cuda.stream(self.side):
-            conv1x1_wgrad(dy, x, like, dw)
+            run()
         self.used = True
         return dw
 
@@ -1000,8 +1025,15 @@ class TransformerBlockFn(torch.autograd.Function):
         # (grad mode is always off INSIDE an autograd Function's forward, and needs_input_grad ignores it: the caller
         # passes `no_grad` = not torch.is_grad_enabled())
         infer = LN_FOLD and bool(no_grad)
+        # training: the same kernel also leaves mean / rstd; the weight gradient normalises x on load again
+        # (conv1x1_wgrad_ln), the LayerNorm backward reads x and the statistics: xn1 / xn2 are neither written nor saved
+        train_fold = LN_TRAIN and not bool(no_grad)
         qkv0 = ln_conv1x1_forward(x, n1w, n1b, wqkv) if infer else None
         xn1 = m1 = r1 = None
+        if train_fold:
+            got = ln_conv1x1_forward(x, n1w, n1b, wqkv, stats=True)
+            if got is not None:
+                qkv0, m1, r1 = got
         if qkv0 is None:
             xn1, m1, r1 = layernorm_forward(x, n1w, n1b)
             qkv0 = conv1x1_forward(xn1, wqkv)
@@ -1019,6 +1051,10 @@ class TransformerBlockFn(torch.autograd.Function):
             x1 = conv1x1_forward(out, wproj, residual=x)
         h0 = ln_conv1x1_forward(x1, n2w, n2b, win) if infer else None
         xn2 = m2 = r2 = None
+        if train_fold:
+            got = ln_conv1x1_forward(x1, n2w, n2b, win, stats=True)
+            if got is not None:
+                h0, m2, r2 = got
         if h0 is None:
             xn2, m2, r2 = layernorm_forward(x1, n2w, n2b)
             h0 = conv1x1_forward(xn2, win)
@@ -1031,13 +1067,13 @@ class TransformerBlockFn(torch.autograd.Function):
         ctx.with_bias = (n1b is not None, n2b is not None)
         ctx.sinks = tuple(_sink(p) for p in (n1w, n1b, temperature, wqkv, wdw1, wproj, n2w, n2b, win, wdw2, wout))
         ctx.save_for_backward(x, n1w, temperature, wqkv, wdw1, wproj, n2w, win, wdw2, wout,
-                              xn1, m1, r1, qkv0, qkv, attn, gram, sumsq, out, x1, xn2, m2, r2, h0, g)
+                              xn1, m1, r1, qkv0, qkv, attn, gram, sumsq, out, x1, xn2, m2, r2, h0, g, n1b, n2b)
         return x2
 
     @staticmethod
     def backward(ctx, dx2):
         (x, n1w, temperature, wqkv, wdw1, wproj, n2w, win, wdw2, wout,
-         xn1, m1, r1, qkv0, qkv, attn, gram, sumsq, out, x1, xn2, m2, r2, h0, g) = ctx.saved_tensors
+         xn1, m1, r1, qkv0, qkv, attn, gram, sumsq, out, x1, xn2, m2, r2, h0, g, n1b, n2b) = ctx.saved_tensors
         s_n1w, s_n1b, s_t, s_qkv, s_dw1, s_proj, s_n2w, s_n2b, s_in, s_dw2, s_out = ctx.sinks
         # The four 1x1 weight gradients feed nothing downstream in this backward: they run on a side stream
         # beside the input-gradient chain (joined before returning).
@@ -1047,7 +1083,7 @@ class TransformerBlockFn(torch.autograd.Function):
         d_wout = side.wgrad(dx2, g, wout, s_out)
         dh0, d_wdw2 = gdfn_dwconv_backward(h0, wdw2, dg, s_dw2)
         del dg
-        d_win = side.wgrad(dh0, xn2, win, s_in)
+        d_win = side.wgrad(dh0, xn2, win, s_in) if xn2 is not None else side.wgrad(dh0, x1, win, s_in, ln=(m2, r2, n2w, n2b))
         fused = conv1x1_dgrad_ln_backward(dh0, win, x1, n2w, m2, r2, s_n2w, s_n2b, dres=dx2) if ctx.with_bias[1] else None
         if fused is None:
             dxn2 = conv1x1_dgrad(dh0, win)
@@ -1067,7 +1103,7 @@ class TransformerBlockFn(torch.autograd.Function):
             del dout
         dqkv0, d_wdw1 = dwconv_backward(dqkv, qkv0, wdw1, s_dw1)
         del dqkv
-        d_wqkv = side.wgrad(dqkv0, xn1, wqkv, s_qkv)
+        d_wqkv = side.wgrad(dqkv0, xn1, wqkv, s_qkv) if xn1 is not None else side.wgrad(dqkv0, x, wqkv, s_qkv, ln=(m1, r1, n1w, n1b))
         fused = conv1x1_dgrad_ln_backward(dqkv0, wqkv, x, n1w, m1, r1, s_n1w, s_n1b, dres=dx1) if ctx.with_bias[0] else None
         if fused is None:
             dxn1 = conv1x1_dgrad(dqkv0, wqkv)

@@ -181,9 +181,40 @@ def test_layernorm_applied_on_load_in_the_no_grad_forward(b, c, cout, h, w):
         _lib.lib.pir_tune_set(24, -1)
     assert y is not None
     close(y, ref, rtol=3e-5)
-    xn, _, _ = ops.layernorm_forward(xd, gd, bd)
+    xn, mean, rstd = ops.layernorm_forward(xd, gd, bd)
     close(y, ops.conv1x1_forward(xn, wd).cpu(), rtol=1e-5)
     assert ops.ln_conv1x1_forward(xd, gd, None, wd) is None      # BiasFree keeps the separate kernels
+    try:                                                          # training form: the statistics come out too
+        _lib.lib.pir_tune_set(24, 1)
+        y2, m2, r2 = ops.ln_conv1x1_forward(xd, gd, bd, wd, stats=True)
+    finally:
+        _lib.lib.pir_tune_set(24, -1)
+    assert torch.equal(y2, y)
+    close(m2, mean.cpu(), rtol=1e-6)
+    close(r2, rstd.cpu(), rtol=2e-6)
+
+
+@pytest.mark.parametrize("b,c,cout,h,w", [(2, 96, 288, 32, 32), (3, 48, 254, 8, 16), (2, 96, 510, 16, 24), (1, 48, 144, 64, 64),
+                                          (2, 96, 100, 8, 8)])
+def test_weight_gradient_with_the_layernorm_applied_on_load(b, c, cout, h, w):
+    """pir_conv1x1_wgrad_ln (gemm_nt_xp_kernel normalising its shared operand as it stages it) vs the weight gradient on
+    the materialised LayerNorm output, and vs autograd on the CPU; (96, 100): a shape the kernel does not serve (fallback)."""
+    from oracle.promptir_ref import layer_norm
+    from promptir_amd import _lib, ops
+
+    x, dy = rnd("x", b, c, h, w) * 3 + 0.5, rnd("dy", b, cout, h, w)
+    gam, bet = rnd("g", c) + 1.5, rnd("b", c)
+    wt = rnd("w", cout, c, 1, 1).requires_grad_(True)
+    F.conv2d(layer_norm(x, gam, bet), wt).backward(dy)
+    xd, dyd, gd, bd, wd = x.to(DEV), dy.to(DEV), gam.to(DEV), bet.to(DEV), wt.detach().to(DEV)
+    xn, mean, rstd = ops.layernorm_forward(xd, gd, bd)
+    try:
+        _lib.lib.pir_tune_set(25, 1)          # serve shapes below the automatic size threshold too
+        dw = ops.conv1x1_wgrad_ln(dyd, xd, mean, rstd, gd, bd, wd)
+    finally:
+        _lib.lib.pir_tune_set(25, -1)
+    close(dw, wt.grad, rtol=5e-5)
+    close(dw, ops.conv1x1_wgrad(dyd, xn, wd).cpu(), rtol=1e-5)
 
 
 @pytest.mark.parametrize("b,c,k,h,w,res", [(2, 96, 288, 32, 32, True), (3, 96, 510, 8, 20, True), (2, 96, 288, 16, 16, False),

@@ -150,8 +150,8 @@ def test_no_grad_forward_with_folded_layernorms_equals_the_training_forward():
     calls = []
     orig = ops.ln_conv1x1_forward
 
-    def spy(*a):
-        out = orig(*a)
+    def spy(*a, **kw):
+        out = orig(*a, **kw)
         calls.append(out is not None)
         return out
 
@@ -165,3 +165,46 @@ def test_no_grad_forward_with_folded_layernorms_equals_the_training_forward():
     y_train = net(x)
     assert float((y_inf - y_train.detach()).abs().max()) <= 2e-6
     assert float((y_inf[:1].cpu() - torch.from_numpy(z["y"])).abs().max()) <= 1e-4
+
+
+def test_training_step_without_the_normalised_tensors_equals_the_step_that_materialises_them(monkeypatch):
+    """Training at batch 8 x 128 x 128: where the persistent kernels serve the shape the forward applies the LayerNorms
+    inside the consuming 1x1 convolutions (statistics written out), the weight gradients normalise x on load again and the
+    LayerNorm backward reads x - xn1 / xn2 never exist.  Loss and every parameter gradient must equal the step that
+    materialises them (PIR_LN_TRAIN=0) to rounding, and the reference's loss."""
+    import json
+
+    from net.model import PromptIR
+    from promptir_amd import ops
+
+    z = util.load_npz("model_small_128.npz")
+    ctor = json.loads(str(z["ctor"]))
+    DEV = torch.device("cuda:0")
+    x = torch.from_numpy(z["x"]).to(DEV).repeat(8, 1, 1, 1)
+    t = torch.roll(x, 1, dims=0) * 0.5
+    results = {}
+    for mode in (True, False):
+        monkeypatch.setattr(ops, "LN_TRAIN", mode)
+        net = PromptIR(**ctor)
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        net.load_state_dict(util.params_for(shapes, int(z["seed"])))
+        net.to(DEV)
+        taken = []
+        orig = ops.ln_conv1x1_forward
+
+        def spy(*a, **kw):
+            out = orig(*a, **kw)
+            taken.append(out is not None and kw.get("stats", False))
+            return out
+
+        monkeypatch.setattr(ops, "ln_conv1x1_forward", spy)
+        loss = (net(x) - t).abs().mean()
+        loss.backward()
+        monkeypatch.setattr(ops, "ln_conv1x1_forward", orig)
+        assert any(taken) == mode
+        results[mode] = (float(loss), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
+    assert abs(results[True][0] - results[False][0]) <= 1e-6
+    for k, ga in results[True][1].items():
+        gb = results[False][1][k]
+        scale = max(float(gb.abs().max()), 1e-12)
+        assert float((ga - gb).abs().max()) <= 1e-3 * scale, k     # two summation orders; accuracy is the golden tests' matter
