@@ -6,8 +6,8 @@
 
 One JSON line on rank 0 (contract in the task statement).  `value` is the whole-job patches/s with
 inputs resident in HBM.  `roofline` describes the dominant kernel family (the kernels behind pir_gemm_nn - tiled gemm_nn_x3_kernel and the
-persistent gemm_nn_bst_kernel / gemm_nn_res_kernel / gemm_nn_cst_kernel: every 1x1 convolution, its input gradient where that is not
-fused with a LayerNorm backward (pir_conv1x1_dgrad_ln_bwd is reported as its own family), and attn@v) measured live with HIP events on the launch
+persistent gemm_nn_bst_kernel / gemm_nn_res_kernel / gemm_nn_cst_kernel: every 1x1 convolution and its input gradient - also where
+the call carries a LayerNorm on load or a LayerNorm backward in its store tail - and attn@v) measured live with HIP events on the launch
 stream in one extra, instrumented step after the timed region.  `cpu_baseline` is the CPU oracle
 (oracle/promptir_ref.py, PyTorch fp32 on the host cores) on a bounded sample of the same workload.
 """
@@ -261,7 +261,13 @@ def main():
             f[0] += 1; f[1] += sec; f[2] += work; f[3] += nbytes
             # this launch's own roofline time: the larger of its MFMA time (bf16x3 ceiling) and its HBM time
             f[4] += max(work / (PEAK_BF16_MFMA_TFLOPS / X3_PASSES * 1e12), nbytes / (PEAK_HBM_GBS * 1e9))
-        calls, secs, flops, gemm_bytes, gemm_bound = fam.get("pir_gemm_nn", [0, 0.0, 0.0, 0.0, 0.0])
+        # the dominant family: the bf16x3 "nn" GEMM kernels = every 1x1 convolution forward and input gradient, whether called
+        # plain (pir_gemm_nn), with the LayerNorm applied on load (pir_ln_conv1x1_fwd) or with the LayerNorm backward in the
+        # store tail (pir_conv1x1_dgrad_ln_bwd); flops and bytes are the GEMM's / the fused call's algorithmic ones
+        calls, secs, flops, gemm_bytes, gemm_bound = 0, 0.0, 0.0, 0.0, 0.0
+        for nm in ("pir_gemm_nn", "pir_ln_conv1x1_fwd", "pir_conv1x1_dgrad_ln_bwd"):
+            f = fam.get(nm, [0, 0.0, 0.0, 0.0, 0.0])
+            calls += f[0]; secs += f[1]; flops += f[2]; gemm_bytes += f[3]; gemm_bound += f[4]
         total = sum(v[1] for v in fam.values())
         achieved = flops / secs / 1e12 if secs > 0 else 0.0
         x3 = ops.USE_X3 and os.environ.get("PIR_NN_X3", "1") != "0"
@@ -278,8 +284,8 @@ def main():
             if fam_t:
                 traffic = round((2.0 * fam_t["fetch_kb_per_launch_raw"] + fam_t["write_kb_per_launch"]) * 1024)
                 traffic_note = "profiles/r03_traffic.json: " + tj["source"] + "; " + tj["note"]
-        roofline = {"kernel": ("gemm_nn_x3_kernel + gemm_nn_bst_kernel + gemm_nn_res_kernel + gemm_nn_cst_kernel<LNB=false>" if x3 else "gemm_nn_kernel") +
-                              " (every kernel behind pir_gemm_nn)",
+        roofline = {"kernel": ("gemm_nn_x3_kernel + gemm_nn_bst_kernel + gemm_nn_res_kernel + gemm_nn_cst_kernel" if x3 else "gemm_nn_kernel") +
+                              " (every kernel behind pir_gemm_nn, pir_ln_conv1x1_fwd and pir_conv1x1_dgrad_ln_bwd)",
                     "bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                     "traffic_note": traffic_note,

@@ -53,6 +53,12 @@ class _TimedLib:
         if name == "pir_conv1x1_dgrad_ln_bwd":     # dy read, x and the residual gradient read, dx written, statistics read
             k, (b, c, hw) = args[4], args[18:21]
             return 4.0 * b * hw * (k + 3 * c + 2)
+        if name == "pir_ln_conv1x1_fwd":           # x read, y written (+ statistics)
+            b, m, k, hw = args[10:14]
+            return 4.0 * b * hw * (k + m + 2)
+        if name == "pir_conv1x1_wgrad_ln":         # dy and x read (+ statistics)
+            b, cout, cin, hw = args[11:15]
+            return 4.0 * b * hw * (cout + cin + 2)
         return 0.0
 
     @staticmethod
@@ -67,6 +73,12 @@ class _TimedLib:
         if name == "pir_conv1x1_dgrad_ln_bwd":
             k, (b, c, hw) = args[4], args[18:21]
             return 2.0 * c * k * hw * b
+        if name == "pir_ln_conv1x1_fwd":
+            b, m, k, hw = args[10:14]
+            return 2.0 * m * k * hw * b
+        if name == "pir_conv1x1_wgrad_ln":
+            b, cout, cin, hw = args[11:15]
+            return 2.0 * cout * cin * hw * b
         if name == "pir_conv3x3":
             b, m, k, h, w = args[11:16]
             return 2.0 * 9 * m * k * h * w * b
@@ -85,7 +97,8 @@ class _TimedLib:
             start.record()
             status = fn(*args)
             end.record()
-            self.records.append((name, start, end, self._work(name, args), self._bytes(name, args)))
+            if status != 1000:      # 1000 = shape not served, nothing launched (the caller runs the unfused pair)
+                self.records.append((name, start, end, self._work(name, args), self._bytes(name, args)))
             return status
 
         return timed

@@ -99,9 +99,9 @@ def is_conv(k):
 fam = {}
 for r in rows:
     k = r["kernel"]
-    if k.startswith("gemm_nn_cst_kernel") and template_args(k)[3] == "true":   # <TM, PK, NW, LNB, MR>: LayerNorm backward fused
-        name = "pir_conv1x1_dgrad_ln_bwd"
-    elif (k.startswith("gemm_nn_x3_kernel") and not is_conv(k)) or k.startswith("gemm_nn_res_kernel") or k.startswith("gemm_nn_bst_kernel") \
+    # the gemm_nn family of bench.py's roofline: every kernel behind pir_gemm_nn, pir_ln_conv1x1_fwd (B-stationary kernel with
+    # the LayerNorm applied on load) and pir_conv1x1_dgrad_ln_bwd (C-stationary kernel with the LayerNorm backward in its tail)
+    if (k.startswith("gemm_nn_x3_kernel") and not is_conv(k)) or k.startswith("gemm_nn_res_kernel") or k.startswith("gemm_nn_bst_kernel") \
             or k.startswith("gemm_nn_cst_kernel"):
         name = "pir_gemm_nn"
     elif k.startswith("gemm_nn_x3_kernel"):

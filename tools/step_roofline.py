@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Per-shape roofline of one instrumented train step: every pir_gemm_nn / pir_gemm_nt / pir_conv1x1_dgrad_ln_bwd call
 with its shape, measured time, and the time its own roofline allows (bf16x3 MFMA ceiling and HBM ceiling).  "fl" rows are
-the input gradients fused with a LayerNorm backward (M = C, K = cout; bytes: dy, x, dres read, dx written)."""
+the input gradients fused with a LayerNorm backward (M = C, K = cout; bytes: dy, x, dres read, dx written), "lf" the forward
+1x1 convolutions with the LayerNorm applied on load (pir_ln_conv1x1_fwd), "wl" the weight gradients that normalise x on load
+(pir_conv1x1_wgrad_ln; M = cout, K = cin)."""
 import argparse
 import os
 import sys
@@ -32,6 +34,7 @@ torch.cuda.synchronize()
 shapes = []
 raw = ops.lib._raw
 orig_nn, orig_nt, orig_fl = raw.pir_gemm_nn, raw.pir_gemm_nt, raw.pir_conv1x1_dgrad_ln_bwd
+orig_lf, orig_wl = raw.pir_ln_conv1x1_fwd, raw.pir_conv1x1_wgrad_ln
 
 
 class Spy:
@@ -43,6 +46,16 @@ class Spy:
             k, (b, c, hw) = a[4], a[18:21]
             st = self.fn(*a)    # 1000 = shape not served (nothing launched): the pair of calls that follows is recorded
             shapes.append((("fl" if st != 1000 else "skip", c, k, hw, b, 1, 1, 0), 2.0 * c * k * hw * b, 4.0 * b * hw * (k + 3 * c + 2)))
+            return st
+        if self.kind == "lf":
+            b, m, k, hw = a[10:14]
+            st = self.fn(*a)
+            shapes.append((("lf" if st != 1000 else "skip", m, k, hw, b, 0, 1, 0), 2.0 * m * k * hw * b, 4.0 * b * hw * (k + m + 2)))
+            return st
+        if self.kind == "wl":
+            b, cout, cin, hw = a[11:15]
+            st = self.fn(*a)
+            shapes.append((("wl" if st != 1000 else "skip", cout, cin, hw, b, 0, 0, 0), 2.0 * cout * cin * hw * b, 4.0 * b * hw * (cout + cin + 2)))
             return st
         g = a[0]._obj
         if self.kind == "nn":
@@ -59,10 +72,12 @@ class Spy:
 
 
 raw.pir_gemm_nn, raw.pir_gemm_nt, raw.pir_conv1x1_dgrad_ln_bwd = Spy(orig_nn, "nn"), Spy(orig_nt, "nt"), Spy(orig_fl, "fl")
+raw.pir_ln_conv1x1_fwd, raw.pir_conv1x1_wgrad_ln = Spy(orig_lf, "lf"), Spy(orig_wl, "wl")
 ops.lib.start_timing()
 tr.train_step(x, t)
-recs = [r for r in ops.lib.stop_timing() if r[0] in ("pir_gemm_nn", "pir_gemm_nt", "pir_conv1x1_dgrad_ln_bwd")]
+recs = [r for r in ops.lib.stop_timing() if r[0] in ("pir_gemm_nn", "pir_gemm_nt", "pir_conv1x1_dgrad_ln_bwd", "pir_ln_conv1x1_fwd", "pir_conv1x1_wgrad_ln")]
 raw.pir_gemm_nn, raw.pir_gemm_nt, raw.pir_conv1x1_dgrad_ln_bwd = orig_nn, orig_nt, orig_fl
+raw.pir_ln_conv1x1_fwd, raw.pir_conv1x1_wgrad_ln = orig_lf, orig_wl
 assert len(recs) == len(shapes), (len(recs), len(shapes))
 agg = {}
 for (name, sec, _, _), (key, flops, byts) in zip(recs, shapes):
@@ -70,7 +85,7 @@ for (name, sec, _, _), (key, flops, byts) in zip(recs, shapes):
         continue
     a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
     a[0] += 1; a[1] += sec; a[2] += flops; a[3] += byts
-tot = {"nn": [0.0, 0.0], "nt": [0.0, 0.0], "fl": [0.0, 0.0]}
+tot = {"nn": [0.0, 0.0], "nt": [0.0, 0.0], "fl": [0.0, 0.0], "lf": [0.0, 0.0], "wl": [0.0, 0.0]}
 print(f"{'kind':3} {'M':>5} {'K':>5} {'N':>6} {'bat':>4} R A3 mf | calls  time_us  bound_us  mfma_us  hbm_us  eff")
 rows = []
 for key, (calls, sec, flops, byts) in agg.items():
