@@ -95,8 +95,8 @@ int pir_conv1x1_wgrad_ln(const float* dy, long dy_bs, const float* x, long x_bs,
  * (net/model.py:60-63 behind :192-196: `self.attn(self.norm1(x))`, `self.ffn(self.norm2(x))`).  The persistent
  * C-stationary kernel (gemm_cst.hip) holds all C channels of a pixel block in one wave, so the gradient of the normalised
  * tensor never leaves its registers (2 of the 4 + 2 C-planes of the unfused pair are not moved).  A3 = pir_split_bf16x3
- * of W [K][C] as the input-gradient operand.  ws: at least 512 C floats.  Served for C = 96, K a multiple-of-96-or-128
- * padded length >= 192, HW % 32 == 0, 16-byte aligned planes; returns 1000 (nothing launched) otherwise and the caller
+ * of W [K][C] as the input-gradient operand.  ws: at least 512 C floats.  Served for C = 48, 96 or 192 with K (padded to 16) a
+ * multiple of the kernel's panel depth, HW % 32 == 0, 16-byte aligned planes; returns 1000 (nothing launched) otherwise and the caller
  * runs pir_gemm_nn + pir_layernorm_bwd. */
 int pir_conv1x1_dgrad_ln_bwd(const float* dy, long dy_bs, const void* A3, int a3_kp, int K,
                              const float* x, long x_bs, const float* ln_w, const float* mean, const float* rstd,
