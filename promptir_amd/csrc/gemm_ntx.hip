@@ -240,7 +240,7 @@ int g_xp_mode = -1;   // knob 25: -1 automatic, 0 never, 1 whenever the shape is
 
 struct XpPlan { int rbw, tn, nwv, splits, rowblocks; };
 
-bool xp_plan(const pir_gemm_nt_t& g, XpPlan& pl) {
+bool xp_plan(const pir_gemm_nt_t& g, XpPlan& pl, bool yln = false) {
   if (g_xp_mode == 0) return false;
   if (g.O1 * g.O2 != 1 || g.H != 0 || g.N % 32 != 0 || g.N < 32) return false;
   if (g.M2 > 96 || g.M2 < 24 || g.M1 < 127) return false;    // (square 96 x 96 / 48 x 48 products: the tiled kernel wins, tools/ntx_ab.py)
@@ -260,7 +260,7 @@ bool xp_plan(const pir_gemm_nt_t& g, XpPlan& pl) {
   long splits = (long)PIR_NUM_CU * (pl.nwv <= 4 ? 2 : 1);
   const long by_work = total / 8 > 0 ? total / 8 : 1;          // at least 256 pixels per slice
   if (splits > by_work) splits = by_work;
-  if (g_xp_mode < 0 && total / splits < 16) return false;      // short pixel ranges: the tiled kernel's finer split wins
+  if (g_xp_mode < 0 && total / splits < (yln ? 8 : 16)) return false;   // short pixel ranges: the tiled kernel's finer split wins
   pl.splits = (int)splits;
   return true;
 }
@@ -282,7 +282,7 @@ int pir_nt_xp_splits(const pir_gemm_nt_t* a) {
 int pir_nt_xp_launch(const pir_gemm_nt_t* a, int* splits, hipStream_t s, const float* y_mean, const float* y_rstd,
                      const float* y_gamma, const float* y_beta) {
   XpPlan pl;
-  if (!xp_plan(*a, pl)) return 1000;
+  if (!xp_plan(*a, pl, y_mean != nullptr)) return 1000;
   if ((size_t)pl.splits * a->M1 * a->M2 > a->ws_floats) return 1000;
   XpArgs xa;
   xa.g = *a;

@@ -632,7 +632,7 @@ static bool bst_plan(const pir_gemm_nn_t& g, BstArgs& a, int& grid, bool ln = fa
   a.panels = (int)pir_cdiv(g.M, bp);
   long wgs = g_res_wgs ? g_res_wgs : PIR_NUM_CU;            // one eight-wave workgroup per CU
   long per = pir_cdiv(pir_cdiv(a.blocks_total, wgs), 8) * 8;
-  if (g_bst_mode < 0 && per < 16) return false;             // at least two rounds per workgroup
+  if (g_bst_mode < 0 && per < (ln ? 8 : 16)) return false;  // at least two rounds per workgroup (one where a LayerNorm launch is replaced too)
   a.per_wg = (int)per;
   grid = (int)pir_cdiv(a.blocks_total, per);
   return true;
