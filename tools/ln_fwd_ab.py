@@ -33,8 +33,12 @@ def main():
                 xn, _, _ = ops.layernorm_forward(x, gam, bet)
                 ops.conv1x1_forward(xn, w)
 
+            if ops.ln_conv1x1_forward(x, gam, bet, w) is None:
+                print(f"C{c} {S}^2 {tag:14s} M={M:4d} | not served at this batch", flush=True)
+                continue
+
             def fused():
-                assert ops.ln_conv1x1_forward(x, gam, bet, w) is not None
+                ops.ln_conv1x1_forward(x, gam, bet, w)
 
             t_p, t_f = timeit([pair, fused])
             print(f"C{c} {S}^2 {tag:14s} M={M:4d} | {t_p*1e6:9.1f} {t_f*1e6:9.1f} {t_f/t_p:6.2f}", flush=True)
