@@ -281,6 +281,8 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
 int g_x3_breg = -1;   // knob 18: activations stay in registers in the one-wave-per-column-block tile (96 x 128): -1 automatic
                       // (planes of <= 4096 pixels: -2..-9 %, bit-identical; neutral to worse at 128^2), 0 never, 1 always
 
+int g_x3_conv_fill = 1;   // pir_tune_set knob 29: narrower dense-3x3 tiles when 96 x 256 leaves the chip underfilled
+
 template <int TM, int TN, int WM, int WN>
 int launch_cfg(const pir_gemm_nn_t& g, hipStream_t s, const X3Conv* conv = nullptr) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -410,7 +412,16 @@ extern "C" int pir_conv3x3_x3(const void* A3, int a3_kp, const float* X, long x_
   if (M <= 64) return launch_cfg<2, 2, 1, 4>(g, s, &cv);
   const long pad96 = pir_cdiv(M, 96) * 96, pad128 = pir_cdiv(M, 128) * 128;
   const long blocks128 = pir_cdiv(M, 128) * pir_cdiv(g.N, 128) * B;
-  if (pad96 <= pad128 && g.N >= 256) return launch_cfg<3, 2, 1, 4>(g, s, &cv);
+  if (pad96 <= pad128 && g.N >= 256) {
+    // the low-resolution convolutions (16^2, 32^2 planes, a part batch of images) give 96 x 256 tiles only 64-128 workgroups
+    // with k loops of 200-430 steps: narrower tiles until the chip is about filled (tools/conv3x3_bench.py)
+    const long wg256 = pir_cdiv(M, 96) * pir_cdiv(g.N, 256) * B, wg128 = pir_cdiv(M, 96) * pir_cdiv(g.N, 128) * B;
+    if (g_x3_conv_fill && wg256 < PIR_NUM_CU) {
+      if (wg128 >= 3L * PIR_NUM_CU / 4) return launch_cfg<3, 1, 1, 4>(g, s, &cv);
+      return launch_cfg<1, 2, 2, 2>(g, s, &cv);
+    }
+    return launch_cfg<3, 2, 1, 4>(g, s, &cv);
+  }
   if (blocks128 < 2L * PIR_NUM_CU && pir_cdiv(M, 64) * 64 <= pad128) return launch_cfg<1, 2, 2, 2>(g, s, &cv);
   return launch_cfg<2, 2, 2, 2>(g, s, &cv);
 }
@@ -435,6 +446,7 @@ int g_x3_narrow96 = 4;   // pir_tune_set knob 5: 96 x 128 instead of 96 x 256 be
 int pir_nn_x3_tune(int knob, int value) {
   if (knob == 5) { g_x3_narrow96 = value; return PIR_OK; }
   if (knob == 18) { g_x3_breg = value; return PIR_OK; }
+  if (knob == 29) { g_x3_conv_fill = value; return PIR_OK; }
   return PIR_EINVAL;
 }
 
