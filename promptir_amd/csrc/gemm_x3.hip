@@ -408,22 +408,31 @@ extern "C" int pir_conv3x3_x3(const void* A3, int a3_kp, const float* X, long x_
   cv.magic_ks = pir_magic((unsigned)cv.ksteps); cv.magic_w = pir_magic((unsigned)W);
   hipStream_t s = (hipStream_t)stream;
   // tile choice as for gemm_nn (rows = output channels, often few)
-  if (M <= 32) return launch_cfg<1, 2, 1, 4>(g, s, &cv);
-  if (M <= 64) return launch_cfg<2, 2, 1, 4>(g, s, &cv);
+  int tile;
   const long pad96 = pir_cdiv(M, 96) * 96, pad128 = pir_cdiv(M, 128) * 128;
   const long blocks128 = pir_cdiv(M, 128) * pir_cdiv(g.N, 128) * B;
-  if (pad96 <= pad128 && g.N >= 256) {
+  if (M <= 32) tile = 1214;
+  else if (M <= 64) tile = 2214;
+  else if (pad96 <= pad128 && g.N >= 256) {
     // the low-resolution convolutions (16^2, 32^2 planes, a part batch of images) give 96 x 256 tiles only 64-128 workgroups
     // with k loops of 200-430 steps: narrower tiles until the chip is about filled (tools/conv3x3_bench.py)
     const long wg256 = pir_cdiv(M, 96) * pir_cdiv(g.N, 256) * B, wg128 = pir_cdiv(M, 96) * pir_cdiv(g.N, 128) * B;
-    if (g_x3_conv_fill && wg256 < PIR_NUM_CU) {
-      if (wg128 >= 3L * PIR_NUM_CU / 4) return launch_cfg<3, 1, 1, 4>(g, s, &cv);
-      return launch_cfg<1, 2, 2, 2>(g, s, &cv);
-    }
-    return launch_cfg<3, 2, 1, 4>(g, s, &cv);
+    tile = 3214;
+    if (g_x3_conv_fill && wg256 < PIR_NUM_CU) tile = wg128 >= 3L * PIR_NUM_CU / 4 ? 3114 : 1222;
+  } else if (blocks128 < 2L * PIR_NUM_CU && pir_cdiv(M, 64) * 64 <= pad128) tile = 1222;
+  else tile = 2222;
+  {   // whole image rows per tile, activations loaded once per row shift (conv_rows.hip) where the shape allows
+    const int st = pir_conv_rows_launch(&g, H, W, tile, s);
+    if (st != 1000) return st;
   }
-  if (blocks128 < 2L * PIR_NUM_CU && pir_cdiv(M, 64) * 64 <= pad128) return launch_cfg<1, 2, 2, 2>(g, s, &cv);
-  return launch_cfg<2, 2, 2, 2>(g, s, &cv);
+  switch (tile) {
+    case 1214: return launch_cfg<1, 2, 1, 4>(g, s, &cv);
+    case 2214: return launch_cfg<2, 2, 1, 4>(g, s, &cv);
+    case 3214: return launch_cfg<3, 2, 1, 4>(g, s, &cv);
+    case 3114: return launch_cfg<3, 1, 1, 4>(g, s, &cv);
+    case 1222: return launch_cfg<1, 2, 2, 2>(g, s, &cv);
+    default: return launch_cfg<2, 2, 2, 2>(g, s, &cv);
+  }
 }
 
 extern "C" size_t pir_split_bf16x3_bytes(int M, int K) {
