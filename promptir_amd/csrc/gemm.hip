@@ -826,9 +826,13 @@ struct NTPlan {
   int splits, chunks_per_r;
 };
 
-NTPlan nt_plan(int M1, int M2, int N, int O, int BR, int bk = NT_BK, bool wide_ok = false) {
+NTPlan nt_plan(int M1, int M2, int N, int O, int BR, int bk = NT_BK, bool wide_ok = false, bool taps = false) {
   NTPlan pl;
-  if (g_nt_cfg >= 0) {
+  if (taps && g_nt_cfg < 0 && M1 <= 64 && M2 > 64) {
+    // dense 3x3 weight gradients with few channels on the row side (down1_2: 48 x 216 virtual rows, prompt1: 64 x 576):
+    // 128-row tiles would be half padding
+    pl.cfg = 6; pl.bm = 64; pl.bn = 128;
+  } else if (g_nt_cfg >= 0) {
     pl.cfg = g_nt_cfg;
     const int c = (g_nt_cfg >= 4 && !(wide_ok && bk == X3_BK)) ? 3 : g_nt_cfg;   // the eight-wave tiles exist for the plain bf16x3 kernel only
     pl.cfg = c;
@@ -874,7 +878,7 @@ int launch_nt(NTParams& p, size_t ws_floats, int tap_sign, long g_st, hipStream_
   const bool x3 = vec4 && (g_nt_x3 != 0 || tap_sign != 0);   // bf16x3 matrix-core path whenever rows are 16-byte aligned
   if (tap_sign != 0 && !x3) return PIR_EINVAL;
   if ((long)g.BR * pir_cdiv(g.N, x3 ? X3_BK : NT_BK) >= 2147483647L) return PIR_EINVAL;   // 32-bit stage counters
-  NTPlan pl = nt_plan(g.M1, g.M2, g.N, O, g.BR, x3 ? X3_BK : NT_BK, x3 && tap_sign == 0);
+  NTPlan pl = nt_plan(g.M1, g.M2, g.N, O, g.BR, x3 ? X3_BK : NT_BK, x3 && tap_sign == 0, tap_sign != 0);
   int xp_splits = 0;
   if (x3 && tap_sign == 0 && g_nt_cfg < 0 && g_nt_splits == 0) {
     // tall x small weight gradients: the tall operand stays private to its wave, only the small one goes through LDS
@@ -896,6 +900,7 @@ int launch_nt(NTParams& p, size_t ws_floats, int tap_sign, long g_st, hipStream_
       case 0: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 1, 2, 2, true>), grid, dim3(256), 0, s, p); break;
       case 1: hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 1, 2, 2, true>), grid, dim3(256), 0, s, p); break;
       case 2: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 3, 4, 1, true>), grid, dim3(256), 0, s, p); break;
+      case 6: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 2, 2, 2, true>), grid, dim3(256), 0, s, p); break;   // 64 x 128
       default: hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2, 2, 2, true>), grid, dim3(256), 0, s, p); break;
     }
   } else if (x3 && (g_nt_quad < 0 ? (g.N >= 1024 && pl.cfg != 1) : g_nt_quad != 0)) {   // sweep: tools/nt_quad_ab.py
@@ -1078,7 +1083,7 @@ extern "C" int pir_gemm_nt(const pir_gemm_nt_t* a, pir_stream_t stream) {
 extern "C" size_t pir_conv3x3_wgrad_ws_floats(int Cout, int Cin, int H, int W, int B) {
   if (Cout <= 0 || Cin <= 0 || H <= 0 || W <= 0 || B <= 0) return 0;
   const int big = Cout > Cin ? Cout : Cin, small = Cout > Cin ? Cin : Cout;
-  NTPlan a = nt_plan(big, 9 * small, H * W, 1, B, X3_BK);
+  NTPlan a = nt_plan(big, 9 * small, H * W, 1, B, X3_BK, false, true);
   const size_t fused = (size_t)a.splits * big * 9 * small;
   const size_t per_tap = pir_gemm_nt_ws_floats(Cout, Cin, H * W, 1, B);
   return fused > per_tap ? fused : per_tap;
