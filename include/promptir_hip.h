@@ -157,7 +157,11 @@ int pir_gemm_nt(const pir_gemm_nt_t* args, pir_stream_t stream);
 /* bf16x3 matrix-core form of pir_conv3x3: A3 = pir_split_bf16x3_taps() of the weights, layout
  * [3 parts][9 taps][a3_kp/16][M][16] bf16 with W(tap, m, k) = W[(flip ? 8-tap : tap)*st + m*sm + k*sk].
  * Forward: st=1, sm=K*9, sk=9, flip=0 on w[M][K][3][3]; input gradient: st=1, sm=9, sk=M*9, flip=1 with the
- * roles of M and K swapped.  Same results as pir_conv3x3 to fp32 rounding (the six-term product drops <= 2^-27). */
+ * roles of M and K swapped.  Same results as pir_conv3x3 to fp32 rounding (the six-term product drops <= 2^-27).
+ * Round 3: where W is a power of two in [16, 256] and the planes are 16-byte aligned, a tile is 128 / 256 pixels of whole
+ * image rows and the activations are loaded once per row shift (conv_rows.hip: the horizontal taps are neighbouring LDS
+ * columns); other widths run the nine-pass kernel.  The taps are then summed in the order (dy, k, dx): same results to
+ * fp32 rounding. */
 int pir_split_bf16x3_taps(const float* W, int M, int K, long st, long sm, long sk, int flip, void* out,
                           pir_stream_t stream);   /* out holds 9 * pir_split_bf16x3_bytes(M, K) bytes */
 int pir_conv3x3_x3(const void* A3, int a3_kp, const float* X, long x_bs, float* Y, long y_bs,
