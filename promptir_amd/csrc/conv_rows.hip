@@ -38,8 +38,12 @@ void conv3x3_rows_kernel(RowsArgs p) {
   constexpr int SB = 6 * BNP;                           // [part][k-group][padded column]
   constexpr int SA = 18 * AKS;                          // [dx][part][k-group][row]
   constexpr int AUN = 18 * BM, NLA = (AUN + T - 1) / T; // weight units per stage / per thread
-  __shared__ bf16x8 sB[SB];
-  __shared__ bf16x8 sA[SA];
+  // two LDS buffers (one barrier per stage, the next stage's conversion in the shadow of this stage's MFMAs) for the
+  // 64 x 128 tile, which serves the underfilled low-resolution launches (one workgroup per CU anyway: -8 %); the other tiles
+  // keep one buffer and two barriers (the 32 x 256 tile measured 10-15 % slower with two: fewer workgroups per CU)
+  constexpr bool DB = WM == 2 && WN == 2 && TM == 1;
+  __shared__ bf16x8 sB[(DB ? 2 : 1) * SB];
+  __shared__ bf16x8 sA[(DB ? 2 : 1) * SA];
   const pir_gemm_nn_t& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WN, wn = wid % WN;
@@ -59,7 +63,7 @@ void conv3x3_rows_kernel(RowsArgs p) {
   // the padding columns (and everything else) of the activation buffer start as zeros and are never written again
   {
     const bf16x8 z = {};
-    for (int u = tid; u < SB; u += T) sB[u] = z;
+    for (int u = tid; u < (DB ? 2 : 1) * SB; u += T) sB[u] = z;
   }
 
   // ---- activations: block i of this wave; lane (h, qj, qk) loads rows 16 ks + 8 h + 4 t + qj, pixels 4 qk .. 4 qk + 3
@@ -83,7 +87,8 @@ void conv3x3_rows_kernel(RowsArgs p) {
         raw[i][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo + 4 * t * ldx4, ks * 16 * ldx4, 0));
     }
   };
-  auto stash_b = [&](f32x4 (&raw)[BPW][2]) {
+  auto stash_b = [&](f32x4 (&raw)[BPW][2], int buf) {
+    bf16x8* sB_ = sB + buf * SB;
 #pragma unroll
     for (int i = 0; i < BPW; ++i) {
       float v[8];
@@ -94,7 +99,7 @@ void conv3x3_rows_kernel(RowsArgs p) {
         v[4 * t] = a0; v[4 * t + 1] = a1; v[4 * t + 2] = a2; v[4 * t + 3] = a3;
       }
       const pir_frag3 fr = pir_split8(v);                 // channels beyond K are zeros (range-checked loads)
-      sB[b_dst[i]] = fr.hi; sB[2 * BNP + b_dst[i]] = fr.mid; sB[4 * BNP + b_dst[i]] = fr.lo;
+      sB_[b_dst[i]] = fr.hi; sB_[2 * BNP + b_dst[i]] = fr.mid; sB_[4 * BNP + b_dst[i]] = fr.lo;
     }
   };
 
@@ -114,10 +119,10 @@ void conv3x3_rows_kernel(RowsArgs p) {
 #pragma unroll
     for (int i = 0; i < NLA; ++i) a[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ars, a_vo[i], so, 0));
   };
-  auto stash_a = [&](const bf16x8 (&a)[NLA]) {
+  auto stash_a = [&](const bf16x8 (&a)[NLA], int buf) {
 #pragma unroll
     for (int i = 0; i < NLA; ++i)
-      if (AUN % T == 0 || a_dst[i] >= 0) sA[a_dst[i]] = a[i];
+      if (AUN % T == 0 || a_dst[i] >= 0) sA[buf * SA + a_dst[i]] = a[i];
   };
 
   f32x16 acc[TM][TN];
@@ -134,16 +139,16 @@ void conv3x3_rows_kernel(RowsArgs p) {
     const int c = wn * TN * 32 + j * 32 + r;
     colp[j] = h * BNP + c + 2 * (c >> p.wshift) + 1;
   }
-  auto compute = [&]() {
+  auto compute = [&](int buf) {
 #pragma unroll
     for (int dxi = 0; dxi < 3; ++dxi) {
-      const bf16x8* ap = sA + dxi * 6 * AKS + h * AKS + wm * TM * 32 + r;
+      const bf16x8* ap = sA + buf * SA + dxi * 6 * AKS + h * AKS + wm * TM * 32 + r;
       bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) { ah[i] = ap[i * 32]; am[i] = ap[2 * AKS + i * 32]; al[i] = ap[4 * AKS + i * 32]; }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const bf16x8* bp = sB + colp[j] + (dxi - 1);      // the horizontal tap: the neighbouring column (or a zero column)
+        const bf16x8* bp = sB + buf * SB + colp[j] + (dxi - 1);   // the horizontal tap: the neighbouring column (or a zero column)
         bh[j] = bp[0]; bm[j] = bp[2 * BNP]; bl[j] = bp[4 * BNP];
       }
 #define PIR_ROWS_TERM(A_, B_)                                                                 \
@@ -163,22 +168,43 @@ void conv3x3_rows_kernel(RowsArgs p) {
   const int stages = 3 * p.ksteps;
   f32x4 raw[BPW][2];
   bf16x8 areg[NLA];
+  int dyi = 0, ks = 0;
+  auto advance = [&](int s) {      // (dyi, ks) -> the stage after s (behind the last stage: its own again, unused)
+    if (s + 1 >= stages) return;
+    if (++ks == p.ksteps) { ks = 0; ++dyi; }
+  };
   load_b(-1, 0, raw);
   load_a(0, 0, areg);
   __syncthreads();                                        // the zero fill is complete
-  int dyi = 0, ks = 0;
-  for (int s = 0; s < stages; ++s) {
-    stash_b(raw);
-    stash_a(areg);
+  if constexpr (DB) {
+    stash_b(raw, 0);
+    stash_a(areg, 0);
+    advance(0);
+    load_b(dyi - 1, ks, raw);
+    load_a(dyi, ks, areg);
     __syncthreads();
-    int nks = ks + 1, ndy = dyi;
-    if (nks == p.ksteps) { nks = 0; ndy = dyi + 1 < 3 ? dyi + 1 : 2; }   // (behind the last stage: its own again, unused)
-    if (s + 1 == stages) nks = ks;
-    load_b(ndy - 1, nks, raw);
-    load_a(ndy, nks, areg);
-    compute();
-    __syncthreads();
-    ks = nks; dyi = ndy;
+    for (int s = 0; s < stages; ++s) {
+      compute(s & 1);
+      if (s + 1 < stages) {                               // stage s + 1 into the other buffer (last read during s - 1)
+        stash_b(raw, (s + 1) & 1);
+        stash_a(areg, (s + 1) & 1);
+      }
+      __syncthreads();
+      advance(s + 1);
+      load_b(dyi - 1, ks, raw);
+      load_a(dyi, ks, areg);
+    }
+  } else {
+    for (int s = 0; s < stages; ++s) {
+      stash_b(raw, 0);
+      stash_a(areg, 0);
+      __syncthreads();
+      advance(s);
+      load_b(dyi - 1, ks, raw);
+      load_a(dyi, ks, areg);
+      compute(0);
+      __syncthreads();
+    }
   }
   pir_nn_epilogue<TM, TN>(acc, g, Y, o1, 0, m0, n0, wm, wn, lane);
 }
