@@ -291,7 +291,7 @@ struct BstArgs {
 template <int KS, int NT, int TP, bool LN = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
 void gemm_nn_bst_kernel(BstArgs p) {
-  constexpr int NW = 8, T = 512, BP = 32 * TP, KG = 2 * KS, PART = KG * BP, PANEL = 3 * PART;
+  constexpr int NW = 8, BP = 32 * TP, KG = 2 * KS, PART = KG * BP, PANEL = 3 * PART;   // 512 threads
   constexpr int NLD = (3 * KS + 1) / 2;       // passes (16-byte units per thread) per panel: two (part, k-step) slices each
   __shared__ bf16x8 smem[2 * PANEL];
   __shared__ f32x4 lnp[LN ? 2 * KS * 4 : 1];  // gamma then beta, K floats each
