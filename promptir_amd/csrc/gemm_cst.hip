@@ -47,17 +47,22 @@ __device__ __forceinline__ float cst_sum_rows(float v) {
 // channels of its 32 pixels, so the LayerNorm backward runs in its registers - with d = dy, xn = (x - mean) rstd,
 // g = d gamma: dx = rstd (g - mean_c(g) - xn mean_c(g xn)) + dres, dgamma += d xn, dbeta += d - and dy is never written.
 // MR: the real row count (48: two 32-row MFMA tiles whose rows 48 .. 63 are zero in LDS and dropped at the store)
-template <int TM, int PK, int NW, bool LNB = false, int MR = 32 * TM>
+// SP = 2 (LNB, 192 rows): the rows of a column block are split between TWO waves (96 each, both stream the same dy block):
+// twice the waves for the few column blocks of a part batch at the 32^2 level (512 blocks against 1024 SIMDs), half the MFMA
+// chain per wave; the two channel sums of the LayerNorm backward are completed through LDS
+template <int TM, int PK, int NW, bool LNB = false, int MR = 32 * TM, int SP = 1>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4)))
 void gemm_nn_cst_kernel(CstArgs p) {
-  constexpr int BM = 32 * TM, T = NW * 64, PF = PK % 4 == 0 ? 4 : 3;
+  constexpr int BM = 32 * TM, PRW = BM * SP, T = NW * 64, PF = PK % 4 == 0 ? 4 : 3, NWB = NW / SP;   // NWB: column blocks per round
+  static_assert(SP == 1 || (LNB && MR == PRW), "row split: fused LayerNorm backward without padding rows");
   constexpr int PUG = PK * MR * 2;            // 16-byte units per part of a panel in global memory (MR rows)
-  constexpr int PU = PK * BM * 2;             // 16-byte units per part of a panel
+  constexpr int PU = PK * PRW * 2;            // 16-byte units per part of a panel
   constexpr int PANEL = 3 * PU;
   constexpr int NLD = (PANEL + T - 1) / T;    // units per thread and panel
   constexpr int NIT = PK * TM;                // (k-step, row tile) iterations per panel
   constexpr int PD = LNB ? (NIT / 4 > 0 ? NIT / 4 : 1) : NIT / 2; // iterations between the load of a panel unit and its LDS write (LNB: fewer registers to park units in)
-  static_assert(PK % PF == 0 && NLD <= NIT - 1, "panel staging");
+  constexpr int LPI = (NLD + NIT - 2) / (NIT - 1);   // panel units loaded per (k-step, row tile) iteration
+  static_assert(PK % PF == 0 && NLD <= LPI * (NIT - 1), "panel staging");
   __shared__ bf16x8 smem[2 * PANEL];
   const pir_gemm_nn_t& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -65,7 +70,8 @@ void gemm_nn_cst_kernel(CstArgs p) {
   const int qk = ((r >> 4) << 2) | (r & 3), qj = (r >> 2) & 3;   // lane -> (pixel quad, row in the quad group)
   const int begin = blockIdx.x * p.per_wg;
   const int end = begin + p.per_wg < p.blocks_total ? begin + p.per_wg : p.blocks_total;
-  const int rounds = (end - begin + NW - 1) / NW;
+  const int rounds = (end - begin + NWB - 1) / NWB;
+  const int half = SP == 1 ? 0 : wid % SP;    // which BM rows of the block this wave owns
   const int ldx4 = (int)g.ldx * 4, ldy = (int)g.ldy, ldr = (int)g.ldr;
   const unsigned xbytes = (unsigned)((((long)g.K - 1) * g.ldx + g.N) * 4);   // rows beyond K read as 0 (range check)
   const unsigned ybytes = (unsigned)((((long)g.M - 1) * g.ldy + g.N) * 4);
@@ -85,7 +91,7 @@ void gemm_nn_cst_kernel(CstArgs p) {
     const int u = tid + idx * T;
     const int part = (u >= PUG) + (u >= 2 * PUG), w = u - part * PUG;
     const int kg = w & 1, rw = (w >> 1) % MR, ksl = (w >> 1) / MR;
-    if ((3 * PUG) % T == 0 || u < 3 * PUG) smem[buf * PANEL + part * PU + (ksl * 2 + kg) * BM + rw] = v;
+    if ((3 * PUG) % T == 0 || u < 3 * PUG) smem[buf * PANEL + part * PU + (ksl * 2 + kg) * PRW + rw] = v;
   };
 
   // ---- activations of a column block: 2 x 16-byte loads per k-step (layout: gemm_nn_res_kernel)
@@ -116,14 +122,14 @@ void gemm_nn_cst_kernel(CstArgs p) {
   };
 
   // first panel, first k-steps of the first block
-  if constexpr (MR < BM) {   // the padding rows of both buffers stay zero for the whole kernel
+  if constexpr (MR < PRW) {  // the padding rows of both buffers stay zero for the whole kernel
     const bf16x8 z = {};
     for (int u = tid; u < 2 * PANEL; u += T) smem[u] = z;
     __syncthreads();
   }
 #pragma unroll
   for (int idx = 0; idx < NLD; ++idx) panel_store(0, idx, panel_load(0, idx));
-  int my = begin + wid;                       // this wave's column block in the current round (clamped by cols())
+  int my = begin + wid / SP;                  // this wave's column block in the current round (clamped by cols())
   Cols cur = cols(my);
 #pragma unroll
   for (int s = 0; s < PF; ++s) {
@@ -134,20 +140,21 @@ void gemm_nn_cst_kernel(CstArgs p) {
   pir_frag3 b = split(raw[0]);
 
   // LNB: gamma of the 4 TM rows this lane holds in the store layout, its partial sums of dgamma / dbeta
-  __shared__ float gsm[LNB ? BM : 1];
+  __shared__ float gsm[LNB ? PRW : 1];
+  __shared__ f32x4 xch[SP == 2 ? NW * 64 * 2 : 1];   // SP = 2: the channel sums of the partner wave
   float pw[TM][4], pb[TM][4];
   if constexpr (LNB) {
-    if (tid < BM) gsm[tid] = tid < MR ? p.gamma[tid] : 0.f;   // (visible behind the prologue's barrier)
+    if (tid < PRW) gsm[tid] = tid < MR ? p.gamma[tid] : 0.f;  // (visible behind the prologue's barrier)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int G = 0; G < 4; ++G) { pw[i][G] = 0.f; pb[i][G] = 0.f; }
   }
 
-  const bf16x8* ap0 = smem + h * BM + r;
+  const bf16x8* ap0 = smem + h * PRW + half * BM + r;
   int gp = 0;                                 // panels consumed so far: panel gp sits in buffer gp & 1
-  for (int round = 0; round < rounds; ++round, my += NW) {
-    const Cols nxt = cols(my + NW);           // (last round: its own block again, unused)
+  for (int round = 0; round < rounds; ++round, my += NWB) {
+    const Cols nxt = cols(my + NWB);          // (last round: its own block again, unused)
     f32x16 acc[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -164,7 +171,7 @@ void gemm_nn_cst_kernel(CstArgs p) {
       auto read_a = [&](int it) {
         const int ksl = it / TM, i = it % TM;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) an[q] = ap[q * PU + ksl * 2 * BM + i * 32];
+        for (int q = 0; q < 3; ++q) an[q] = ap[q * PU + ksl * 2 * PRW + i * 32];
       };
       read_a(0);
       bf16x8 stage[NLD];
@@ -187,14 +194,20 @@ void gemm_nn_cst_kernel(CstArgs p) {
           const int it = ksl * TM + i;
           const bf16x8 ah = an[0], am = an[1], al = an[2];
           if (it + 1 < NIT) read_a(it + 1);
-          if (it < NLD) stage[it] = panel_load(npi, it);
-          if (it >= PD && it - PD < NLD) panel_store(buf ^ 1, it - PD, stage[it - PD]);
+#pragma unroll
+          for (int q = it * LPI; q < (it + 1) * LPI; ++q)
+            if (q < NLD) stage[q] = panel_load(npi, q);
+          if (it >= PD) {
+#pragma unroll
+            for (int q = (it - PD) * LPI; q < (it - PD + 1) * LPI; ++q)
+              if (q < NLD) panel_store(buf ^ 1, q, stage[q]);
+          }
           acc[i] = pir_mfma_x3(ah, am, al, c.hi, c.mid, c.lo, acc[i]);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int q = (NIT - PD > 0 ? NIT - PD : 0); q < NLD; ++q) panel_store(buf ^ 1, q, stage[q]);
+      for (int q = (NIT - PD > 0 ? NIT - PD : 0) * LPI; q < NLD; ++q) panel_store(buf ^ 1, q, stage[q]);
       __syncthreads();   // the next panel is complete in the other buffer; everyone is done reading this one
     }
 
@@ -206,14 +219,14 @@ void gemm_nn_cst_kernel(CstArgs p) {
       const int bb = active ? my : end - 1;
       const int o = pir_fastdiv(bb, p.magic_nbpi), nb = (bb - o * p.nbpi) * 32;
       const __amdgpu_buffer_rsrc_t yrs = pir_make_rsrc(g.Y + (long)o * g.y_s1, active ? ybytes : 0u);
-      const int vy = ((4 * h + qj) * ldy + nb + 4 * qk) * 4;
+      const int vy = ((half * BM + 4 * h + qj) * ldy + nb + 4 * qk) * 4;
       const int n4 = g.N * 4;
       const unsigned pbytes = (unsigned)((long)MR * n4);
       const __amdgpu_buffer_rsrc_t xrs = pir_make_rsrc(p.lx + (long)o * p.lx_bs, pbytes);
       const __amdgpu_buffer_rsrc_t drs = pir_make_rsrc(p.dres ? p.dres + (long)o * p.dres_bs : p.lx, p.dres ? pbytes : 0u);
       const __amdgpu_buffer_rsrc_t mrs = pir_make_rsrc(p.mean + (long)o * g.N, (unsigned)n4);
       const __amdgpu_buffer_rsrc_t srs = pir_make_rsrc(p.rstd + (long)o * g.N, (unsigned)n4);
-      const int vx = ((4 * h + qj) * g.N + nb + 4 * qk) * 4;
+      const int vx = ((half * BM + 4 * h + qj) * g.N + nb + 4 * qk) * 4;
       const f32x4 mu = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mrs, (nb + 4 * qk) * 4, 0, 0));
       const f32x4 rs = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, (nb + 4 * qk) * 4, 0, 0));
       f32x4 xv[TM][4];
@@ -234,14 +247,20 @@ void gemm_nn_cst_kernel(CstArgs p) {
           const f32x4 t = d * xn;
           pw[i][G] += actf * ((t[0] + t[1]) + (t[2] + t[3]));
           pb[i][G] += actf * ((d[0] + d[1]) + (d[2] + d[3]));
-          const f32x4 gg = d * gsm[32 * i + 8 * G + 4 * h + qj];
+          const f32x4 gg = d * gsm[half * BM + 32 * i + 8 * G + 4 * h + qj];
           s1 += gg; s2 += gg * xn;
           xv[i][G] = xn;
           acc[i][4 * G] = gg[0]; acc[i][4 * G + 1] = gg[1]; acc[i][4 * G + 2] = gg[2]; acc[i][4 * G + 3] = gg[3];
         }
       f32x4 m1, m2;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { m1[e] = cst_sum_rows(s1[e]) * (1.f / (float)MR); m2[e] = cst_sum_rows(s2[e]) * (1.f / (float)MR); }
+      for (int e = 0; e < 4; ++e) { m1[e] = cst_sum_rows(s1[e]); m2[e] = cst_sum_rows(s2[e]); }
+      if constexpr (SP == 2) {   // the other half of the channels: the partner wave's sums (every wave of the workgroup is here)
+        xch[(wid * 64 + lane) * 2] = m1; xch[(wid * 64 + lane) * 2 + 1] = m2;
+        __syncthreads();
+        m1 += xch[((wid ^ 1) * 64 + lane) * 2]; m2 += xch[((wid ^ 1) * 64 + lane) * 2 + 1];
+      }
+      m1 *= 1.f / (float)MR; m2 *= 1.f / (float)MR;
       // the residual gradient arrives one row tile ahead of its use (all of it at once would not fit the registers)
       f32x4 rv[2][4];
 #pragma unroll
@@ -303,8 +322,8 @@ void gemm_nn_cst_kernel(CstArgs p) {
         w += __shfl_xor(w, 2, 64); bsum += __shfl_xor(bsum, 2, 64);
         w += __shfl_xor(w, 16, 64); bsum += __shfl_xor(bsum, 16, 64);
         if (qk == 0) {
-          const int row = 32 * i + 8 * G + 4 * h + qj;
-          red[(wid * 2) * BM + row] = w; red[(wid * 2 + 1) * BM + row] = bsum;
+          const int row = half * BM + 32 * i + 8 * G + 4 * h + qj;
+          red[(wid * 2) * PRW + row] = w; red[(wid * 2 + 1) * PRW + row] = bsum;
         }
       }
     __syncthreads();
@@ -312,13 +331,16 @@ void gemm_nn_cst_kernel(CstArgs p) {
       const int which = t / MR, c = t - which * MR;
       float sum = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) sum += red[(w * 2 + which) * BM + c];
+      for (int w = 0; w < NW; ++w)
+        if (SP == 1 || w % SP == c / BM) sum += red[(w * 2 + which) * PRW + c];   // (SP = 2: the waves that own this half)
       p.ws[(long)blockIdx.x * 2 * MR + t] = sum;
     }
   }
 }
 
 int g_cst_mode = -1;   // knob 26: -1 automatic, 0 never, 1 whenever the shape is served
+int g_cst_split = 0;      // knob 32: 192-channel fused LayerNorm backward with the rows of a block split between two waves
+                          // (isolated 0.78 of the one-wave variant's time, no effect inside the two-stream step: off)
 int g_cst_ln_maxc = 192;   // knob 27: most channels the fused LayerNorm backward serves (A/B of the 192-channel variant)
 
 bool cst_plan(const pir_gemm_nn_t& g, CstArgs& a, int& grid, int& pk, bool lnb = false) {
@@ -328,8 +350,9 @@ bool cst_plan(const pir_gemm_nn_t& g, CstArgs& a, int& grid, int& pk, bool lnb =
   if (g.M != 96 && g.M != 192 && g.M != 48) return false;
   const int kp = (int)(pir_cdiv(g.K, 16) * 16), ks = kp / 16;
   if (g.a3_kp != kp || ks < (g.M == 48 ? 8 : 12)) return false;
-  // 96 rows: eight waves, panels of 8 or 6 k-steps; 192 rows: four waves (all registers of a SIMD to one wave), panels of 4
-  const int nw = g.M == 96 ? 8 : 4;
+  // 96 rows: eight waves, panels of 8 or 6 k-steps; 192 rows: four waves (all registers of a SIMD to one wave), panels of 4;
+  // fused LayerNorm backward at 192 rows: the rows of a block split between two waves, two blocks per round and workgroup
+  const int nw = g.M == 96 || g.M == 48 ? 8 : (lnb && g_cst_split ? 2 : 4);
   pk = g.M == 192 ? (ks % 4 == 0 ? 4 : 0) : g.M == 48 ? (ks % 8 == 0 ? 8 : ks == 9 ? 9 : 0) : ks % 8 == 0 ? 8 : ks % 6 == 0 ? 6 : 0;
   if (!pk) return false;
   // plain 192-row products (32^2 level) gain nothing over the tiled kernel (tools/cst_ab.py: 0.99-1.05 at batch 32, half
@@ -356,7 +379,7 @@ bool cst_plan(const pir_gemm_nn_t& g, CstArgs& a, int& grid, int& pk, bool lnb =
 }  // namespace
 
 int pir_nn_cst_tune(int knob, int value) {
-  if (knob == 26) g_cst_mode = value; else if (knob == 27) g_cst_ln_maxc = value; else return PIR_EINVAL;
+  if (knob == 26) g_cst_mode = value; else if (knob == 27) g_cst_ln_maxc = value; else if (knob == 32) g_cst_split = value; else return PIR_EINVAL;
   return PIR_OK;
 }
 
@@ -406,6 +429,7 @@ extern "C" int pir_conv1x1_dgrad_ln_bwd(const float* dy, long dy_bs, const void*
   if (C == 48 && pk == 9) hipLaunchKernelGGL((gemm_nn_cst_kernel<2, 9, 8, true, 48>), dim3((unsigned)grid), dim3(512), 0, s, a);
   else if (C == 48 && pk == 8) hipLaunchKernelGGL((gemm_nn_cst_kernel<2, 8, 8, true, 48>), dim3((unsigned)grid), dim3(512), 0, s, a);
   else if (C == 48) return 1000;
+  else if (C == 192 && g_cst_split) hipLaunchKernelGGL((gemm_nn_cst_kernel<3, 4, 4, true, 192, 2>), dim3((unsigned)grid), dim3(256), 0, s, a);
   else if (C == 192) hipLaunchKernelGGL((gemm_nn_cst_kernel<6, 4, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
   else if (pk == 8) hipLaunchKernelGGL((gemm_nn_cst_kernel<3, 8, 8, true>), dim3((unsigned)grid), dim3(512), 0, s, a);
   else hipLaunchKernelGGL((gemm_nn_cst_kernel<3, 6, 8, true>), dim3((unsigned)grid), dim3(512), 0, s, a);
