@@ -248,6 +248,35 @@ def main():
                    "ms_per_step": round(e5 / args.steps * 1e3, 3), "per_gpu_value": round(8 * args.steps / e5, 3)}
         trainer.prepare(x, t)      # back to the headline shape for the instrumented step below
 
+    # N > 1 (VERDICT r3 #6b): the same steps in BOTH gradient-exchange modes, so that the first run on real xGMI decides the
+    # default: "single" = one graph + one exposed all-reduce of the 142 MB flat gradient, "staged" = three segment graphs
+    # with the all-reduce of each finished range overlapping the next segment.  Headline batch and config 5's batch 8.
+    staged_ab = None
+    if world > 1 or os.environ.get("PIR_BENCH_STAGED_AB") == "1":
+        default_mode = trainer.staged
+        staged_ab = {"default": "staged" if default_mode else "single"}
+        shapes = [("batch%d" % args.batch, x, t)] + ([("batch8", *build_batch(8, args.patch, rank, device))] if args.batch != 8 else [])
+        for mode in (False, True):
+            if trainer.set_staged(mode) != mode:
+                continue
+            for tag, xb, tb in shapes:
+                trainer.prepare(xb, tb)
+                for _ in range(max(1, args.warmup)):
+                    trainer.train_step(xb, tb)
+                sync()
+                ta = time.perf_counter()
+                for _ in range(args.steps):
+                    trainer.train_step(xb, tb)
+                sync()
+                ea = time.perf_counter() - ta
+                if world > 1:
+                    tm = torch.tensor([ea], dtype=torch.float64, device=device)
+                    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                    ea = float(tm.item())
+                staged_ab["%s_%s_ms" % ("staged" if mode else "single", tag)] = round(ea / args.steps * 1e3, 3)
+        trainer.set_staged(default_mode)
+        trainer.prepare(x, t)
+
     roofline, cpu = None, None
     # one extra instrumented step: HIP events around every C-ABI call on the launch stream.  Every rank runs it (the
     # step holds the gradient all-reduce, and the replicas must stay in step); rank 0 reports its own records.
@@ -261,29 +290,70 @@ def main():
             f[0] += 1; f[1] += sec; f[2] += work; f[3] += nbytes
             # this launch's own roofline time: the larger of its MFMA time (bf16x3 ceiling) and its HBM time
             f[4] += max(work / (PEAK_BF16_MFMA_TFLOPS / X3_PASSES * 1e12), nbytes / (PEAK_HBM_GBS * 1e9))
+
+        def group(pred):
+            tot = [0, 0.0, 0.0, 0.0, 0.0]
+            for k, v in fam.items():
+                if pred(k.split("@")[0], k.split("@")[1] if "@" in k else None):
+                    tot = [a + b for a, b in zip(tot, v)]
+            return tot
+
         # the dominant family: the bf16x3 "nn" GEMM kernels = every 1x1 convolution forward and input gradient, whether called
         # plain (pir_gemm_nn), with the LayerNorm applied on load (pir_ln_conv1x1_fwd) or with the LayerNorm backward in the
         # store tail (pir_conv1x1_dgrad_ln_bwd); flops and bytes are the GEMM's / the fused call's algorithmic ones
-        calls, secs, flops, gemm_bytes, gemm_bound = 0, 0.0, 0.0, 0.0, 0.0
-        for nm in ("pir_gemm_nn", "pir_ln_conv1x1_fwd", "pir_conv1x1_dgrad_ln_bwd"):
-            f = fam.get(nm, [0, 0.0, 0.0, 0.0, 0.0])
-            calls += f[0]; secs += f[1]; flops += f[2]; gemm_bytes += f[3]; gemm_bound += f[4]
+        calls, secs, flops, gemm_bytes, gemm_bound = group(
+            lambda n, tag: n in ("pir_gemm_nn", "pir_ln_conv1x1_fwd", "pir_conv1x1_dgrad_ln_bwd"))
         total = sum(v[1] for v in fam.values())
         achieved = flops / secs / 1e12 if secs > 0 else 0.0
         x3 = ops.USE_X3 and os.environ.get("PIR_NN_X3", "1") != "0"
         # bf16x3: each fp32-class product costs 6 bf16 MFMA passes, so the ceiling for ALGORITHMIC flops is
         # bf16 peak / 6; `frac` is then the MFMA-pipe utilisation.  The fp32-MFMA figure is kept beside it.
         peak = PEAK_BF16_MFMA_TFLOPS / X3_PASSES if x3 else PEAK_F32_MFMA_TFLOPS
-        # HBM bytes per launch from the committed PMC profile of this build (rocprofv3 cannot run inside the timed
-        # process): FETCH_SIZE x 2 (gfx950 wide-read correction) + WRITE_SIZE, averaged over the family's launches
-        traffic, traffic_note = None, None
-        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
+
+        def family(pred, bound):
+            """One family of the instrumented step against its roofline: `hbm` - algorithmic bytes / event time / 8 TB/s;
+            `mfma` - algorithmic flops / event time / the bf16x3 ceiling; both carry the per-launch max(MFMA, HBM) bound."""
+            n, sec, fl, by, bnd = group(pred)
+            if n == 0 or sec <= 0:
+                return None
+            out = {"bound": bound, "abi_calls": n, "ms": round(sec * 1e3, 3),
+                   "frac_of_per_launch_bound": round(bnd / sec, 4)}
+            if bound == "hbm":
+                out.update(achieved=round(by / sec / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(by / sec / 1e9 / PEAK_HBM_GBS, 4))
+            else:
+                out.update(achieved=round(fl / sec / 1e12, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(fl / sec / 1e12 / peak, 4),
+                           algorithmic_gbs=round(by / sec / 1e9, 1))
+            return out
+
+        STENCILS = ("pir_dwconv3x3_sumsq", "pir_dwconv3x3", "pir_dwconv3x3_gate", "pir_dwconv3x3_bwd", "pir_gdfn_dwconv_bwd")
+        families = {
+            # north_star: "stated fraction of HBM roofline for depthwise": algorithmic planes x 4 B (SURVEY 8d, DESIGN 4)
+            "depthwise_stencils": family(lambda n, tag: n in STENCILS, "hbm"),
+            **{"depthwise:" + k: family(lambda n, tag, k=k: n == k, "hbm") for k in STENCILS if any(f.split("@")[0] == k for f in fam)},
+            # north_star: "... and of MFMA roofline for MDTA": q k^T, attn v (folded into project_out where the fold runs) and
+            # their backward products dW_eff, dv, dq, dk - the calls ops.py files under the "mdta" tag
+            "mdta_contractions": family(lambda n, tag: tag == "mdta" and n in ("pir_gemm_nn", "pir_gemm_nt", "pir_mdta_dqk"), "mfma"),
+            # every weight gradient over the pixels that is not an MDTA product
+            "weight_gradients": family(lambda n, tag: tag != "mdta" and n in ("pir_gemm_nt", "pir_conv1x1_wgrad_ln", "pir_conv3x3_wgrad"), "mfma"),
+            "dense_conv3x3": family(lambda n, tag: n in ("pir_conv3x3", "pir_conv3x3_x3"), "mfma"),
+        }
+        # HBM bytes from the committed PMC profile of this build (rocprofv3 cannot run inside the timed process):
+        # per launch of the dominant family (FETCH_SIZE x its calibrated factor + WRITE_SIZE) and summed over the whole step
+        traffic, traffic_note, step_bytes = None, None, None
+        tpath = os.path.join(ROOT, "profiles", "r04_traffic.json")
+        if not os.path.exists(tpath):
+            tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
         if x3 and args.batch == 32 and os.path.exists(tpath):
             tj = json.load(open(tpath))
             fam_t = tj["families"].get("pir_gemm_nn")
             if fam_t:
-                traffic = round((2.0 * fam_t["fetch_kb_per_launch_raw"] + fam_t["write_kb_per_launch"]) * 1024)
-                traffic_note = "profiles/r03_traffic.json: " + tj["source"] + "; " + tj["note"]
+                fx = fam_t.get("fetch_factor", 2.0)
+                traffic = round((fx * fam_t["fetch_kb_per_launch_raw"] + fam_t["write_kb_per_launch"]) * 1024)
+                traffic_note = os.path.relpath(tpath, ROOT) + ": " + tj["source"] + "; " + tj["note"]
+            step_bytes = tj.get("step_bytes")
+        lpath = os.path.join(ROOT, "profiles", "r04_step_launches.json")
+        launches = json.load(open(lpath)).get("batch%d" % args.batch) if os.path.exists(lpath) else None
+        step_s = elapsed / args.steps
         roofline = {"kernel": ("gemm_nn_x3_kernel + gemm_nn_bst_kernel + gemm_nn_res_kernel + gemm_nn_cst_kernel" if x3 else "gemm_nn_kernel") +
                               " (every kernel behind pir_gemm_nn, pir_ln_conv1x1_fwd and pir_conv1x1_dgrad_ln_bwd)",
                     "bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
@@ -298,6 +368,15 @@ def main():
                     "algorithmic_gbs": round(gemm_bytes / secs / 1e9, 1) if secs > 0 else None, "hbm_peak_gbs": PEAK_HBM_GBS,
                     "launches_per_step": calls, "avg_launch_us": round(secs / max(calls, 1) * 1e6, 2),
                     "share_of_step_kernel_time": round(secs / total, 4) if total > 0 else None,
+                    "families": {k: v for k, v in families.items() if v is not None},
+                    # the whole step: HBM bytes of one step from the committed counter passes (sum over every kernel of
+                    # calibrated FETCH_SIZE + WRITE_SIZE) over THIS run's step time, against the 8 TB/s peak
+                    "bytes_per_step": step_bytes,
+                    "step_frac_of_hbm": round(step_bytes / step_s / (PEAK_HBM_GBS * 1e9), 4) if step_bytes else None,
+                    "step_launches": {"abi_calls_instrumented_step": len(recs),
+                                      "kernel_launches_per_step": launches,
+                                      "note": "kernel launches per graph step, share under 10 us and kernels outside the library: "
+                                              "profiles/r04_step_launches.json (tools/step_kernels.py over a rocprofv3 kernel trace)"},
                     "families_ms": {k: round(v[1] * 1e3, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}}
         if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N=1 only
             cpu = cpu_baseline(sd, args.patch)
@@ -340,7 +419,9 @@ def main():
                        "world": world, "device_index": local, "replica_param_spread": spread,
                        "staged_backward": bool(trainer.staged),
                        "gradient_ranges_bytes": [[4 * lo, 4 * hi] for lo, hi in (trainer.opt.stages or [])],
-                       "params": 35592263, "final_loss": float(loss), "step1_loss_check": loss_check},
+                       "params": 35592263, "final_loss": float(loss), "step1_loss_check": loss_check,
+                       # everything that can change which kernels ran: module switches, PIR_* environment, tuning knobs
+                       "kernel_selection": ops.effective_switches(), "staged_ab": staged_ab},
             "per_gpu_value": round(patches / elapsed / world, 3),
             "roofline": roofline, "cpu_baseline": cpu, "config5": config5, "inference": inference, "tiled_512": tiled,
         }

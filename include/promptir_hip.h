@@ -44,10 +44,12 @@ const char* pir_arch(void);
  * set them before the first launch, never while another thread is launching. */
 int pir_tune_set(int knob, int value);
 
-/* 0 for the product build.  Bit 0 would mean a diagnostic build (kernels with pipeline components removed, results
- * garbage): those macros no longer exist in the sources and pir_common.h refuses them; tests/test_cabi.py checks the
- * shipped library reports 0.  Every remaining pir_tune_set knob selects between kernels / plans with identical results
- * (tile plan, split count, band height); none skips work. */
+/* Self-description of the LOADED library, derived from compile-time state: bit 0 = a diagnostic macro was defined
+ * (kernels with pipeline components removed, results garbage; those macros no longer exist in the sources and
+ * pir_common.h refuses them, so a product build has the bit clear), bits 8..23 = the ABI version the object was
+ * compiled with, bit 24 = built with --offload-arch=gfx950.  tests/test_cabi.py checks all three against the binding.
+ * Every remaining pir_tune_set knob selects between kernels / plans with identical results (tile plan, split count,
+ * band height); none skips work. */
 int pir_build_flags(void);
 
 /* ------------------------------------------------------------------ GEMM core
@@ -320,13 +322,14 @@ int pir_tiles_blend(const float* tiles, float* out, long out_bs, int B, int C, i
                     int Hout, int Wout, int clamp01, pir_stream_t stream);
 
 /* ------------------------------------------------------------------ loss, copies, optimiser
- * nn.L1Loss() (train.py:32,43): loss = mean|a-b|; optional fused grad = sign(a-b)/count * gscale
- * (grad may be NULL). ws: 1024 floats. */
-int pir_l1_loss(const float* restored, const float* clean, float* loss, float* grad, float gscale,
+ * nn.L1Loss() (train.py:32,43): loss = lscale * mean|a-b|; optional fused grad = sign(a-b)/count * gscale
+ * (grad may be NULL). ws: 1024 floats.  lscale / scale: a part batch's share of the whole batch, passed BY VALUE
+ * (the data-parallel trainer cuts a batch into parts on their own streams; with 1 the result is the plain mean). */
+int pir_l1_loss(const float* restored, const float* clean, float* loss, float* grad, float gscale, float lscale,
                 float* ws, long count, pir_stream_t stream);
 /* backward of the same loss with the upstream scalar gradient read from device memory:
- * grad = sign(restored-clean) * dloss[0] / count */
-int pir_l1_loss_grad(const float* restored, const float* clean, const float* dloss, float* grad,
+ * grad = sign(restored-clean) * dloss[0] * scale / count */
+int pir_l1_loss_grad(const float* restored, const float* clean, const float* dloss, float scale, float* grad,
                      long count, pir_stream_t stream);
 /* GPU-side Gaussian degradation in the uint8 domain (utils/degradation_utils.py:21-27):
  * out = uint8(clip(floor(clean*255) + N(0,1)*sigma[b], 0, 255)) / 255 with the counter-based generator of
@@ -336,6 +339,10 @@ int pir_degrade_gaussian(const float* clean, float* out, const float* sigma, con
 /* y[b][c][n] = x[b][c][n] (+ y if accumulate) for channel-slice copies (torch.cat, net/model.py:341-370) */
 int pir_copy_planes(const float* x, long x_bs, float* y, long y_bs, int accumulate,
                     int B, long plane_floats, pir_stream_t stream);
+/* y (contiguous [B][C][H][W]) = x read through four free element strides: layout repair for a permuted / channels-last
+ * view handed to the module surface (the reference's callers pass contiguous NCHW) */
+int pir_copy_strided4(const float* x, long s0, long s1, long s2, long s3, float* y, int B, int C, int H, int W,
+                      pir_stream_t stream);
 /* out[i] = a[i] + b[i] */
 int pir_add(const float* a, const float* b, float* out, long count, pir_stream_t stream);
 

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PIR_LIB", os.path.join(_HERE, "libpromptir_hip.so"))  # PIR_LIB: A/B builds in tools/
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_float_p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 c_long = C.c_long
@@ -97,8 +97,9 @@ SIGNATURES = {
     "pir_prompt_mix_bwd": (I, [P, P, P, P, P, P, P, L, I, I, I, I, I, S]),
     "pir_tiles_gather": (I, [P, L, P, I, I, I, I, I, I, I, I, I, I, I, I, I, S]),
     "pir_tiles_blend": (I, [P, P, L, I, I, I, I, I, I, I, I, I, I, I, I, I, S]),
-    "pir_l1_loss": (I, [P, P, P, P, F, P, L, S]),
-    "pir_l1_loss_grad": (I, [P, P, P, P, L, S]),
+    "pir_l1_loss": (I, [P, P, P, P, F, F, P, L, S]),
+    "pir_l1_loss_grad": (I, [P, P, P, F, P, L, S]),
+    "pir_copy_strided4": (I, [P, L, L, L, L, P, I, I, I, I, S]),
     "pir_degrade_gaussian": (I, [P, P, P, P, L, I, S]),
     "pir_copy_planes": (I, [P, L, P, L, I, I, L, S]),
     "pir_add": (I, [P, P, P, L, S]),

@@ -18,13 +18,14 @@ __global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict
   if (threadIdx.x == 0) ws[blockIdx.x] = t;
 }
 
-__global__ __launch_bounds__(256) void l1_final_kernel(const float* __restrict__ ws, int n, float inv_count,
+__global__ __launch_bounds__(256) void l1_final_kernel(const float* __restrict__ ws, int n, float inv_count, float lscale,
                                                        float* __restrict__ loss) {
   __shared__ float red[16];
   float s = 0.f;
   for (int i = threadIdx.x; i < n; i += blockDim.x) s += ws[i];
   const float t = pir_block_sum(s, red);
-  if (threadIdx.x == 0) loss[0] = t * inv_count;
+  // (t * inv_count) first: with lscale == 1 the value is the plain mean, bit for bit
+  if (threadIdx.x == 0) loss[0] = (t * inv_count) * lscale;
 }
 
 // grad = sign(a-b) * (*dloss) / count : backward of the mean-absolute-error with the upstream
@@ -36,6 +37,16 @@ __global__ __launch_bounds__(256) void l1_grad_kernel(const float* __restrict__ 
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
     const float d = a[i] - b[i];
     grad[i] = d > 0.f ? gval : (d < 0.f ? -gval : 0.f);
+  }
+}
+
+// dst (contiguous NCHW) = src read through four free strides: the layout repair of the operator layer (a permuted or
+// channels-last view handed to the module surface) as a library kernel instead of an ATen copy.
+__global__ __launch_bounds__(256) void copy_strided4_kernel(const float* __restrict__ x, long s0, long s1, long s2, long s3,
+                                                            float* __restrict__ y, int C, int H, int W, long total) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long w = e % W, t1 = e / W, h = t1 % H, t2 = t1 / H, c = t2 % C, b = t2 / C;
+    y[e] = x[b * s0 + c * s1 + h * s2 + w * s3];
   }
 }
 
@@ -184,10 +195,10 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 }  // namespace
 
-extern "C" int pir_abi_version(void) { return 7; }
+extern "C" int pir_abi_version(void) { return 8; }
 extern "C" const char* pir_arch(void) { return "gfx950"; }
 
-extern "C" int pir_l1_loss(const float* restored, const float* clean, float* loss, float* grad, float gscale,
+extern "C" int pir_l1_loss(const float* restored, const float* clean, float* loss, float* grad, float gscale, float lscale,
                            float* ws, long count, pir_stream_t stream) {
   PIR_CHECK_ARG(restored && clean && loss && ws && count > 0);
   hipStream_t s = (hipStream_t)stream;
@@ -195,15 +206,23 @@ extern "C" int pir_l1_loss(const float* restored, const float* clean, float* los
   hipLaunchKernelGGL(l1_partial_kernel, dim3(blocks), dim3(256), 0, s, restored, clean, grad, gscale / (float)count, ws, count);
   int st = pir_launch_status();
   if (st) return st;
-  hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, s, ws, blocks, 1.f / (float)count, loss);
+  hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, s, ws, blocks, 1.f / (float)count, lscale, loss);
   return pir_launch_status();
 }
 
-extern "C" int pir_l1_loss_grad(const float* restored, const float* clean, const float* dloss, float* grad,
+extern "C" int pir_l1_loss_grad(const float* restored, const float* clean, const float* dloss, float scale, float* grad,
                                 long count, pir_stream_t stream) {
   PIR_CHECK_ARG(restored && clean && dloss && grad && count > 0);
   hipLaunchKernelGGL(l1_grad_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream,
-                     restored, clean, dloss, 1.f / (float)count, grad, count);
+                     restored, clean, dloss, scale / (float)count, grad, count);
+  return pir_launch_status();
+}
+
+extern "C" int pir_copy_strided4(const float* x, long s0, long s1, long s2, long s3, float* y, int B, int C, int H, int W,
+                                 pir_stream_t stream) {
+  PIR_CHECK_ARG(x && y && B > 0 && C > 0 && H > 0 && W > 0);
+  const long total = (long)B * C * H * W;
+  hipLaunchKernelGGL(copy_strided4_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, s0, s1, s2, s3, y, C, H, W, total);
   return pir_launch_status();
 }
 
@@ -268,8 +287,19 @@ extern "C" int pir_adamw_step(float* param, const float* grad, float* exp_avg, f
   return pir_launch_status();
 }
 
-// Build self-description for tests (tests/test_cabi.py): bit 0 = a diagnostic / ablation build (never: pir_common.h
-// refuses those macros), bits 8.. = the gfx950 code object this file was compiled for.
+// Build self-description of the LOADED library, derived from compile-time state (tests/test_cabi.py compares it with
+// what the sources say): bit 0 = a diagnostic / ablation macro was defined (pir_common.h refuses those, so a product
+// build reports 0 here), bits 8..23 = the ABI version this object was compiled with, bit 24 = the device pass of this
+// translation unit targeted gfx950 (read from a kernel-side constant the host copy of which is patched by the compiler's
+// own target macro).
+#if defined(X3_ABLATE) || defined(NT_ABLATE) || defined(X3_TRACE) || defined(PIR_DIAG)
+#define PIR_FLAG_DIAG 1
+#else
+#define PIR_FLAG_DIAG 0
+#endif
+#ifndef PIR_BUILD_ARCH_GFX950   /* the Makefile passes -DPIR_BUILD_ARCH_GFX950=1 together with --offload-arch=gfx950 */
+#define PIR_BUILD_ARCH_GFX950 0
+#endif
 extern "C" int pir_build_flags(void) {
-  return 0;
+  return PIR_FLAG_DIAG | (8 << 8) | (PIR_BUILD_ARCH_GFX950 ? (1 << 24) : 0);
 }

@@ -59,6 +59,31 @@ class _TimedLib:
         if name == "pir_conv1x1_wgrad_ln":         # dy and x read (+ statistics)
             b, cout, cin, hw = args[11:15]
             return 4.0 * b * hw * (cout + cin + 2)
+        if name == "pir_conv3x3_wgrad":            # dy and x read once
+            b, cout, cin, h, w = args[5:10]
+            return 4.0 * b * h * w * (cout + cin)
+        if name in ("pir_conv3x3", "pir_conv3x3_x3"):   # x read, y written (+ residual)
+            b, m, k, h, w = args[11:16] if name == "pir_conv3x3" else args[8:13]
+            return 4.0 * b * h * w * (k + m)
+        # ---- depthwise stencils (HBM roofline): algorithmic planes x 4 bytes, SURVEY 8(d) / DESIGN 4
+        if name == "pir_dwconv3x3_sumsq":          # x read, y written
+            b, c, h, w = args[9:13]
+            return 4.0 * 2 * b * c * h * w
+        if name == "pir_dwconv3x3":
+            b, c, h, w = args[6:10]
+            return 4.0 * 2 * b * c * h * w
+        if name == "pir_dwconv3x3_gate":           # both halves of x read, g written: 3 planes per hidden channel
+            b, hid, h, w = args[5:9]
+            return 4.0 * 3 * b * hid * h * w
+        if name == "pir_dwconv3x3_bwd":            # dy and x read, dx written
+            b, c, h, w = args[10:14]
+            return 4.0 * 3 * b * c * h * w
+        if name == "pir_gdfn_dwconv_bwd":          # x (2 planes) and dg read, dx (2 planes) written: 5 per hidden channel
+            b, hid, h, w = args[10:14]
+            return 4.0 * 5 * b * hid * h * w
+        if name == "pir_mdta_dqk":                 # q, k read; dq, dk written
+            b, heads, c, hw = args[9:13]
+            return 4.0 * 4 * b * heads * c * hw
         return 0.0
 
     @staticmethod
@@ -85,6 +110,12 @@ class _TimedLib:
         if name == "pir_conv3x3_x3":
             b, m, k, h, w = args[8:13]
             return 2.0 * 9 * m * k * h * w * b
+        if name == "pir_conv3x3_wgrad":
+            b, cout, cin, h, w = args[5:10]
+            return 2.0 * 9 * cout * cin * h * w * b
+        if name == "pir_mdta_dqk":                 # dq = dG k and dk = dG^T q
+            b, heads, c, hw = args[9:13]
+            return 2.0 * 2 * c * c * hw * b * heads
         return 0.0
 
     def __getattr__(self, name):
@@ -98,24 +129,68 @@ class _TimedLib:
             status = fn(*args)
             end.record()
             if status != 1000:      # 1000 = shape not served, nothing launched (the caller runs the unfused pair)
-                self.records.append((name, start, end, self._work(name, args), self._bytes(name, args)))
+                label = name + "@" + _TAG[-1] if _TAG else name
+                self.records.append((label, start, end, self._work(name, args), self._bytes(name, args)))
             return status
 
         return timed
 
 
+_TAG = []   # innermost `tagged(...)` scope: the instrumented step files a call under "<entry point>@<tag>"
+
+
+class tagged:
+    """Scope whose C-ABI calls the instrumented step reports as a family of their own (bench.py: the MDTA contractions
+    are generic pir_gemm_nn / pir_gemm_nt calls; north_star wants their MFMA fraction by itself)."""
+
+    def __init__(self, tag: str):
+        self.tag = tag
+
+    def __enter__(self):
+        _TAG.append(self.tag)
+
+    def __exit__(self, *exc):
+        _TAG.pop()
+        return False
+
+
+def _tag_calls(tag: str):
+    def deco(fn):
+        def wrapped(*a, **k):
+            with tagged(tag):
+                return fn(*a, **k)
+        wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
+        return wrapped
+    return deco
+
+
 lib = _TimedLib(_lib.lib)
+_KNOBS_SET = {}   # knob -> value of every pir_tune_set this process made through `tune_set` (reported by bench.py)
+
+
+def tune_set(knob: int, value: int) -> None:
+    check(_lib.lib.pir_tune_set(int(knob), int(value)), "pir_tune_set(%s=%s)" % (knob, value))
+    _KNOBS_SET[int(knob)] = int(value)
+
+
+def effective_switches() -> dict:
+    """Everything that can change which kernels the product path runs: the module switches below, every PIR_*
+    environment variable and every tuning knob set in this process.  bench.py prints it with its line."""
+    mod = {k: globals()[k] for k in ("USE_X3", "MDTA_FOLD", "LN_FOLD", "LN_TRAIN", "DGRAD_LN", "MDTA_DQK", "MDTA_FOLD_MIN_HW",
+                                      "USE_SIDE_STREAM", "CAT_INPLACE", "SHUFFLE_FOLD", "NT_GROUP") if k in globals()}
+    return {"switches": mod, "env": {k: v for k, v in sorted(_os.environ.items()) if k.startswith("PIR_")},
+            "knobs_set": {str(k): v for k, v in sorted(_KNOBS_SET.items())}}
 
 # A/B switches for development (tools/, tests): PIR_NN_X3 = 0 | 1 forces the fp32-MFMA / bf16x3 gemm_nn path
 import os as _os
 
 if _os.environ.get("PIR_NN_X3") is not None:
-    _lib.lib.pir_tune_set(3, int(_os.environ["PIR_NN_X3"]))
+    tune_set(3, int(_os.environ["PIR_NN_X3"]))
 if _os.environ.get("PIR_NT_X3") is not None:
-    _lib.lib.pir_tune_set(4, int(_os.environ["PIR_NT_X3"]))
+    tune_set(4, int(_os.environ["PIR_NT_X3"]))
 for _kv in filter(None, _os.environ.get("PIR_KNOBS", "").split(",")):   # "20=0,25=0": any pir_tune_set knob (tools A/B)
     _k, _v = _kv.split("=")
-    check(_lib.lib.pir_tune_set(int(_k), int(_v)), "pir_tune_set(%s)" % _kv)
+    tune_set(int(_k), int(_v))
 
 
 # ----------------------------------------------------------------------------- plumbing
@@ -136,7 +211,8 @@ def _stream() -> int:
 
 
 def _planes(t: torch.Tensor) -> torch.Tensor:
-    """Return `t` if it satisfies the plane layout (free batch stride), else a contiguous copy."""
+    """Return `t` if it satisfies the plane layout (free batch stride), else a contiguous copy made by the library's
+    own gather kernel (pir_copy_strided4) - never an ATen copy: the step holds pir_* kernels only."""
     if t.dim() != 4:
         raise RuntimeError(f"expected a 4-d NCHW tensor, got shape {tuple(t.shape)}")
     b, c, h, w = t.shape
@@ -144,7 +220,33 @@ def _planes(t: torch.Tensor) -> torch.Tensor:
     ok = (w == 1 or st[3] == 1) and (h == 1 or st[2] == w) and (c == 1 or st[1] == h * w)
     if ok and (b == 1 or st[0] >= c * h * w):
         return t
-    return t.contiguous()
+    return _gather_contiguous(t)
+
+
+def _gather_contiguous(t: torch.Tensor) -> torch.Tensor:
+    _require_gpu(t)
+    b, c, h, w = t.shape
+    out = torch.empty((b, c, h, w), dtype=torch.float32, device=t.device)
+    st = t.stride()
+    check(lib.pir_copy_strided4(t.data_ptr(), st[0], st[1], st[2], st[3], out.data_ptr(), b, c, h, w, _stream()),
+          "pir_copy_strided4")
+    return out
+
+
+def _contig4(t: torch.Tensor) -> torch.Tensor:
+    """Fully contiguous NCHW (the flat-indexed kernels: loss)."""
+    return t if t.is_contiguous() else _gather_contiguous(t)
+
+
+def copy_flat(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """dst[:] = src for contiguous fp32 buffers of equal size through pir_copy_planes (a tensor.copy_() would be a
+    runtime blit kernel outside the library)."""
+    _require_gpu(src, dst)
+    if not (src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()):
+        raise RuntimeError("copy_flat: contiguous buffers of equal size expected")
+    check(lib.pir_copy_planes(src.data_ptr(), src.numel(), dst.data_ptr(), dst.numel(), 0, 1, src.numel(), _stream()),
+          "pir_copy_planes")
+    return dst
 
 
 def _bs(t: torch.Tensor) -> int:
@@ -627,14 +729,16 @@ def mdta_attn_forward(qkv: torch.Tensor, temperature: torch.Tensor, heads: int, 
         check(lib.pir_row_sumsq(qkv.data_ptr(), bs, sumsq.data_ptr(), b, 2 * c_all, hw, _stream()), "pir_row_sumsq")
     nparts = sumsq.shape[1]
     gram = torch.empty((b, heads, c, c), dtype=torch.float32, device=dev)
-    gemm_nt(qkv, 0, (bs, c * hw, 0), hw, qkv, c_all * hw, (bs, c * hw, 0), hw, gram, 0, (c * c, c, 1),
-            c, c, hw, b, heads, 1)
+    with tagged("mdta"):
+        gemm_nt(qkv, 0, (bs, c * hw, 0), hw, qkv, c_all * hw, (bs, c * hw, 0), hw, gram, 0, (c * c, c, 1),
+                c, c, hw, b, heads, 1)
     attn = torch.empty_like(gram)
     check(lib.pir_mdta_softmax_fwd(gram.data_ptr(), sumsq.data_ptr(), nparts, temperature.data_ptr(), attn.data_ptr(),
                                    b, heads, c, _stream()), "pir_mdta_softmax_fwd")
     return attn, gram, sumsq
 
 
+@_tag_calls("mdta")
 def mdta_attn_backward(dattn, qkv, temperature, heads, attn, gram, sumsq, dqkv, dtemp_out=None):
     """From dattn to dq, dk (written into the q / k thirds of `dqkv`) and dtemperature: backward through softmax,
     temperature and the two L2 normalisations (net/model.py:127-131)."""
@@ -674,6 +778,7 @@ def mdta_attn_backward(dattn, qkv, temperature, heads, attn, gram, sumsq, dqkv, 
     return dtemp
 
 
+@_tag_calls("mdta")
 def mdta_core_forward(qkv: torch.Tensor, temperature: torch.Tensor, heads: int, sumsq: Optional[torch.Tensor] = None):
     """From qkv = dw3x3(1x1(x)) to out = softmax(norm(q) norm(k)^T * t) v (net/model.py:121-135)."""
     qkv = _planes(qkv)
@@ -689,6 +794,7 @@ def mdta_core_forward(qkv: torch.Tensor, temperature: torch.Tensor, heads: int, 
     return out, attn, gram, sumsq
 
 
+@_tag_calls("mdta")
 def mdta_core_backward(dout, qkv, temperature, heads, attn, gram, sumsq, dtemp_out=None):
     dout, qkv = _planes(dout), _planes(qkv)
     b, c3, h, w = qkv.shape
@@ -717,6 +823,7 @@ def mdta_core_backward(dout, qkv, temperature, heads, attn, gram, sumsq, dtemp_o
 #        gradient over the pixels, no dattn = dout v^T, no dv = attn^T dout), followed by C x C x c sized products
 #        dW_proj[:, h-block] = sum_b dW_eff_b[:, h-block] attn_{b,h}^T,   dattn_{b,h} = W_proj[:, h-block]^T dW_eff_b[:, h-block].
 #      `out` is never materialised (C planes less to write, read and keep for the backward).
+@_tag_calls("mdta")
 def mdta_fold_forward(qkv, attn, wproj, x_res, heads):
     b, c3, h, w = qkv.shape
     C = c3 // 3
@@ -733,6 +840,7 @@ def mdta_fold_forward(qkv, attn, wproj, x_res, heads):
     return x1, weff
 
 
+@_tag_calls("mdta")
 def mdta_fold_backward(dx1, qkv, attn, weff, wproj, heads, dqkv, dwproj_out=None):
     """Writes dv into the v third of `dqkv`, returns (dattn, dW_proj)."""
     dx1 = _planes(dx1)
@@ -960,6 +1068,7 @@ MDTA_FOLD_MIN_HW = int(_os.environ.get("PIR_MDTA_FOLD_MIN_HW", "4096"))   # ... 
 # C x C x c products it adds cost as much as the launch-bound GEMMs it removes: bench A/B, round 2)
 _SIDE_STREAMS = {}
 _SIDE_OVERRIDE = []   # innermost `side_streams(...)` scope wins over the module default
+_CAPTURE_MAINS = set()   # main streams on which a side-stream block backward ran inside the CURRENT stream capture
 
 
 class side_streams:
@@ -992,6 +1101,21 @@ class _SideWgrads:
         self.main = torch.cuda.current_stream(device)
         self.side = None
         if _side_stream_enabled() and lib.records is None:   # the instrumented (timed) step stays on one stream
+            # Side streams under ONE capturing stream are fine (the trainer's single-stream graph does it).  Under a
+            # capture that spans SEVERAL part streams, each forking its own side stream, the round-3 build died with a
+            # host segfault inside graph capture (each wgrad forks + joins a fourth-level stream, records
+            # its operands on it - block frees of a capturing pool are deferred per recorded stream - and creates
+            # two events per call; with two origin streams the capture held ~190 cross-stream edges per part).  The
+            # fault was never bisected on hardware; the combination is refused instead of risked:
+            if torch.cuda.is_current_stream_capturing():
+                _CAPTURE_MAINS.add(self.main.cuda_stream)
+                if len(_CAPTURE_MAINS) > 1:
+                    raise RuntimeError(
+                        "promptir_amd: weight-gradient side streams inside a stream capture that spans more than one "
+                        "part stream are not supported (host crash in capture, DESIGN 4); wrap the step in "
+                        "ops.side_streams(False) or capture on a single stream")
+            else:
+                _CAPTURE_MAINS.clear()
             key = (device.index, self.main.cuda_stream)   # one side stream per main stream (two-stream training)
             self.side = _SIDE_STREAMS.get(key)
             if self.side is None:
@@ -1059,8 +1183,9 @@ class TransformerBlockFn(torch.autograd.Function):
             out = torch.empty_like(x)
             b_, c_all, hw_ = x.shape[0], x.shape[1], x.shape[2] * x.shape[3]
             c_ = c_all // heads
-            gemm_nn(attn, (heads * c_ * c_, c_ * c_), c_, 1, qkv, 2 * c_all * hw_, (_bs(qkv), c_ * hw_), hw_,
-                    out, 0, (c_all * hw_, c_ * hw_), hw_, c_, c_, hw_, b_, heads)
+            with tagged("mdta"):
+                gemm_nn(attn, (heads * c_ * c_, c_ * c_), c_, 1, qkv, 2 * c_all * hw_, (_bs(qkv), c_ * hw_), hw_,
+                        out, 0, (c_all * hw_, c_ * hw_), hw_, c_, c_, hw_, b_, heads)
             x1 = conv1x1_forward(out, wproj, residual=x)
         h0 = ln_conv1x1_forward(x1, n2w, n2b, win) if infer else None
         xn2 = m2 = r2 = None
@@ -1190,9 +1315,15 @@ class ForkFn(torch.autograd.Function):
         # block's dx), the other usually a channel slice of the concat's gradient (free batch stride): the slice is
         # accumulated into the fresh one by the plane-copy kernel, no copy, no third buffer.  The fresh tensor is an
         # intermediate of this backward with this node as its only consumer.
-        if not da.is_contiguous() and db.is_contiguous():
+        # Autograd does not promise exclusive ownership of an incoming gradient: accumulate in place only into a
+        # tensor that owns its storage (no view: at batch 1 a channel slice of the concat gradient is contiguous too)
+        # and is not the other operand.
+        def owned(t):
+            return t.is_contiguous() and t._base is None
+
+        if not owned(da) and owned(db) and da is not db:
             da, db = db, da
-        if not da.is_contiguous():
+        if not owned(da) or da is db or da.untyped_storage().data_ptr() == db.untyped_storage().data_ptr():
             out = torch.empty(da.shape, dtype=torch.float32, device=da.device)
             copy_planes(da, out)
             da = out
@@ -1255,28 +1386,45 @@ class L1LossFn(torch.autograd.Function):
     """nn.L1Loss() (train.py:32,43); the gradient is produced in the same pass as the loss."""
 
     @staticmethod
-    def forward(ctx, restored, clean):
+    def forward(ctx, restored, clean, weight):
         _require_gpu(restored, clean)
-        restored, clean = restored.contiguous(), clean.contiguous()
+        restored, clean = _contig4(restored), _contig4(clean)
         loss = torch.empty((), dtype=torch.float32, device=restored.device)
         ws = workspace(1024, restored.device, slot="loss")
-        check(lib.pir_l1_loss(restored.data_ptr(), clean.data_ptr(), loss.data_ptr(), None, 1.0,
+        check(lib.pir_l1_loss(restored.data_ptr(), clean.data_ptr(), loss.data_ptr(), None, 1.0, float(weight),
                               ws.data_ptr(), restored.numel(), _stream()), "pir_l1_loss")
         ctx.save_for_backward(restored, clean)
+        ctx.weight = float(weight)
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
         restored, clean = ctx.saved_tensors
         grad = torch.empty_like(restored)
-        dloss = dloss.contiguous()
-        check(lib.pir_l1_loss_grad(restored.data_ptr(), clean.data_ptr(), dloss.data_ptr(), grad.data_ptr(),
+        if dloss.numel() != 1:
+            raise RuntimeError("L1LossFn.backward: scalar upstream gradient expected")
+        check(lib.pir_l1_loss_grad(restored.data_ptr(), clean.data_ptr(), dloss.data_ptr(), ctx.weight, grad.data_ptr(),
                                    restored.numel(), _stream()), "pir_l1_loss_grad")
-        return grad, None
+        return grad, None, None
 
 
-def l1_loss(restored: torch.Tensor, clean: torch.Tensor) -> torch.Tensor:
-    return L1LossFn.apply(restored, clean)
+def l1_loss(restored: torch.Tensor, clean: torch.Tensor, weight: float = 1.0) -> torch.Tensor:
+    """`weight` * nn.L1Loss()(restored, clean): the weight (a part batch's share of the whole batch) travels by value into
+    both kernels, so neither the forward nor the backward needs a device scalar of its own."""
+    return L1LossFn.apply(restored, clean, weight)
+
+
+_ONES = {}
+
+
+def unit_gradient(device) -> torch.Tensor:
+    """A persistent device scalar 1.0 to seed `loss.backward(gradient=...)`: the implicit seed of `loss.backward()` is
+    an ATen fill kernel per call (and a fresh allocation inside a captured graph)."""
+    key = torch.device(device).index
+    t = _ONES.get(key)
+    if t is None:
+        t = _ONES[key] = torch.ones((), dtype=torch.float32, device=device)
+    return t
 
 
 def add_(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:

@@ -39,13 +39,16 @@ def warmup_cosine_lr(epoch: int, base_lr: float = 2e-4, warmup_epochs: int = 15,
 def lightning_epoch_lr(epoch: int, **kw) -> float:
     """Learning rate the reference actually TRAINS epoch `epoch` with under Lightning 2.0.1.
 
-    `lr_scheduler_step` (train.py:48-50) calls `scheduler.step(self.current_epoch)`.  Lightning's
-    `FitLoop.on_advance_end` runs `update_lr_schedulers("epoch", ...)` at the END of epoch N, before
-    `epoch_progress.increment_completed()`, and `trainer.current_epoch` is `epoch_progress.current.completed`: the
-    call made at the end of epoch N passes N, so epoch N+1 trains with closed_form(N); epoch 0 trains with the
-    scheduler's construction-time value closed_form(0) = warmup_start_lr = 0.  Epochs 0 and 1 therefore both run
-    with lr 0.  (Lightning is not installed in the build container; this ordering is restated from the 2.0.1
-    sources as recorded in ADVICE round 1 and is not executed anywhere here.)"""
+    `lr_scheduler_step` (train.py:48-50) calls `scheduler.step(self.current_epoch)`.  For an epoch-interval,
+    non-plateau scheduler Lightning 2.0.1 makes that call from `_TrainingEpochLoop.advance`, right after the LAST batch
+    of the epoch (`if self._num_ready_batches_reached(): self.update_lr_schedulers("epoch",
+    update_plateau_schedulers=False)`), i.e. BEFORE `FitLoop.on_advance_end` fires `on_train_epoch_end` /
+    ModelCheckpoint; the later call in `on_advance_end` has `update_plateau_schedulers=True` and skips a cosine
+    scheduler.  `trainer.current_epoch` is `epoch_progress.current.completed`, still N while epoch N runs: the call at
+    the end of epoch N passes N, so epoch N+1 trains with closed_form(N), and epoch 0 trains with the scheduler's
+    construction-time value closed_form(0) = warmup_start_lr = 0.  Epochs 0 and 1 therefore both run with lr 0.
+    (Lightning is not installed in the build container; this ordering is restated from the 2.0.1 sources as recorded in
+    ADVICE rounds 1 and 3 and is not executed anywhere here.)"""
     return warmup_cosine_lr(max(epoch - 1, 0), **kw)
 
 
@@ -221,6 +224,9 @@ class DataParallelTrainer:
         self.opt = FlatAdamW(net, lr=lr)
         if dist.is_initialized():  # DDP's initial parameter broadcast from rank 0 (a 1-rank group runs it too)
             dist.broadcast(self.opt.param, src=0)
+        # the library's L1 takes a part batch's share of the batch BY VALUE (no device scalar, no ATen fill / multiply
+        # in the step); a caller-supplied loss_fn(y, t) is weighted through the upstream gradient instead
+        self._own_loss = loss_fn is None
         if loss_fn is None:
             from .ops import l1_loss as loss_fn
         self.loss_fn = loss_fn
@@ -256,6 +262,37 @@ class DataParallelTrainer:
                 for i in range(n):
                     self._sinks[i].append((p, self._grads[i][o:o + p.numel()].view_as(p)))
 
+    def _part_loss(self, y: torch.Tensor, t: torch.Tensor, share: float):
+        """(loss node, upstream gradient): with the library's own L1 the node already holds share * mean|y - t| and the
+        seed is a persistent device 1.0; otherwise the share travels as the upstream gradient."""
+        if self._own_loss and y.is_cuda:
+            from . import ops
+
+            return self.loss_fn(y, t, share), ops.unit_gradient(y.device)
+        return self.loss_fn(y, t), torch.full((), share, dtype=torch.float32, device=y.device)
+
+    def _total_loss(self, parts) -> torch.Tensor:
+        """Sum of the parts' shares of the batch loss (mean over the batch), on the device."""
+        total = None
+        for loss, w in parts:
+            if self._own_loss and loss.is_cuda:
+                from . import ops
+
+                total = loss.detach() if total is None else ops.add_(total, loss.detach())
+            else:
+                total = loss.detach() * w if total is None else total + loss.detach() * w
+        return total
+
+    def set_staged(self, staged: bool) -> bool:
+        """Switch between ONE graph + ONE all-reduce of the flat gradient (False) and the backward in three segment
+        graphs with the all-reduce of each finished gradient range overlapping the next segment (True).  Drops the
+        captured graph: the next step re-captures.  Returns the mode now in effect (the staged mode needs the module's
+        three-piece forward)."""
+        staged = bool(staged) and self.opt.param.is_cuda and self._staged_ok()
+        if staged != self.staged:
+            self.staged, self._graph, self._graph_shape, self._seg_state = staged, None, None, None
+        return self.staged
+
     def _use_sinks_default(self) -> None:
         for n, p in self.opt.named:
             o = self.opt.offsets[n]
@@ -280,8 +317,8 @@ class DataParallelTrainer:
         b = degrad_patch.shape[0]
         n = min(self.micro_streams, max(1, b // 4))      # parts of at least four samples
         if not (two_streams and n > 1):
-            loss = self.loss_fn(self.net(degrad_patch), clean_patch)
-            loss.backward()
+            loss, seed = self._part_loss(self.net(degrad_patch), clean_patch, 1.0)
+            loss.backward(gradient=seed)
             return loss.detach()
         from . import ops
 
@@ -296,8 +333,7 @@ class DataParallelTrainer:
             st.wait_event(ready)
             self._use_sinks(i)                       # captured by the autograd nodes of this forward
             with torch.cuda.stream(st):
-                w = torch.full((), (hi - lo) / b, dtype=torch.float32, device=degrad_patch.device)
-                losses.append((self.loss_fn(self.net(degrad_patch[lo:hi]), clean_patch[lo:hi]), w))
+                losses.append(self._part_loss(self.net(degrad_patch[lo:hi]), clean_patch[lo:hi], (hi - lo) / b))
         for i, (loss, w) in enumerate(losses):
             with torch.cuda.stream(self._streams[i]):
                 loss.backward(gradient=w)
@@ -306,12 +342,9 @@ class DataParallelTrainer:
             done.record(st)
             main.wait_event(done)
         self._use_sinks(0)
-        total = None
-        for i, (loss, w) in enumerate(losses):      # mean over the batch = sum of the weighted parts
-            if i:
-                ops.add_(self.opt.grad, self._grads[i])
-            total = loss.detach() * w if total is None else total + loss.detach() * w
-        return total
+        for i in range(1, len(losses)):
+            ops.add_(self.opt.grad, self._grads[i])
+        return self._total_loss(losses)             # mean over the batch = sum of the weighted parts
 
     # ---- gradient all-reduce overlapped with backward (reference: DDP's bucketed all-reduce, train.py:339) ----------
     # The forward is cut into three pieces (PromptIR.encode_levels | run_latent | decode); the backward then runs as
@@ -371,9 +404,9 @@ class DataParallelTrainer:
                 lat = self.net.run_latent(enc_cut[3])
                 lat_cut = lat.detach().requires_grad_()
                 y = self.net.decode(x[lo:hi], lat_cut, enc_cut[2], enc_cut[1], enc_cut[0])
-                w = torch.full((), (hi - lo) / b, dtype=torch.float32, device=x.device)
+                loss, w = self._part_loss(y, t[lo:hi], (hi - lo) / b)
                 self._seg_state.append({"enc": enc, "enc_cut": enc_cut, "lat": lat, "lat_cut": lat_cut,
-                                        "loss": self.loss_fn(y, t[lo:hi]), "w": w})
+                                        "loss": loss, "w": w})
         for p, st in zip(self._seg_state, streams):
             with torch.cuda.stream(st):
                 p["loss"].backward(gradient=p["w"])
@@ -381,10 +414,7 @@ class DataParallelTrainer:
         if n > 1:
             self._use_sinks(0)
         self._sum_range(2, n)
-        total = None
-        for p in self._seg_state:                    # mean over the batch = sum of the weighted parts
-            total = p["loss"].detach() * p["w"] if total is None else total + p["loss"].detach() * p["w"]
-        return total
+        return self._total_loss([(p["loss"], p["w"]) for p in self._seg_state])   # mean over the batch
 
     def _seg_latent(self, device) -> None:
         """Segment 1: backward of the latent blocks (stage 1's range)."""
@@ -523,11 +553,13 @@ class DataParallelTrainer:
             if sig != self._split_sig:
                 ops.refresh_split_weights()
                 self._split_sig = ops.split_weights_signature()
-            self._sx.copy_(degrad_patch)
-            self._st.copy_(clean_patch)
+            if degrad_patch.data_ptr() != self._sx.data_ptr():   # (a caller may fill the static buffers itself)
+                ops.copy_flat(ops._contig4(degrad_patch), self._sx)
+            if clean_patch.data_ptr() != self._st.data_ptr():
+                ops.copy_flat(ops._contig4(clean_patch), self._st)
             if self.staged:        # three segment graphs; `between(stage)` runs after the segment that completes `stage`
                 self._graph[0].replay()
-                loss = self._sloss.clone()
+                loss = self._loss_out()
                 if between:
                     between(2)
                 self._graph[1].replay()
@@ -536,11 +568,23 @@ class DataParallelTrainer:
                 self._graph[2].replay()
                 return loss
             self._graph.replay()
-            return self._sloss.clone()
+            return self._loss_out()
         if self.staged and ops.lib.records is None:
             return self._staged_eager(degrad_patch, clean_patch, between)
         # eager; the instrumented (per-kernel timed) step stays on one stream
         return self._fwd_bwd(degrad_patch, clean_patch, two_streams=ops.lib.records is None)
+
+    def static_inputs(self):
+        """The captured graph's own input buffers (degraded, clean) once a graph exists: a loader that writes its batch
+        straight into them (device-side degradation, crop and augmentation kernels) saves the per-step copy."""
+        return (self._sx, self._st) if self._graph is not None else None
+
+    def _loss_out(self) -> torch.Tensor:
+        """The replayed step's loss in a tensor of its own, copied out of the graph's static scalar by the library's
+        copy kernel (a `.clone()` is a runtime blit outside the library)."""
+        from . import ops
+
+        return ops.copy_flat(self._sloss, torch.empty_like(self._sloss))
 
     def train_step(self, degrad_patch: torch.Tensor, clean_patch: torch.Tensor, lr: Optional[float] = None):
         """reference train.py:37-46 (+ optimizer.step of Lightning's loop)."""
@@ -581,12 +625,14 @@ class DataParallelTrainer:
         `lr_schedulers[0]` the LinearWarmupCosineAnnealingLR state, plus the version / loops / callbacks keys
         `load_from_checkpoint` and `trainer.fit(ckpt_path=...)` look up (loop progress is not tracked here: `loops`
         and `callbacks` are empty, so Lightning restarts its counters from `epoch` / `global_step`)."""
-        cur_lr = self.opt.lr if lr is None else lr
-        # Lightning's ModelCheckpoint saves in on_train_epoch_end, BEFORE update_lr_schedulers of that epoch: at the
-        # epoch-N save the scheduler has seen step(0..N-1) plus its construction-time step, so last_epoch = N-1,
-        # _step_count = N+1 and _last_lr is the rate epoch N trained with (lightning_epoch_lr(N))
+        # ModelCheckpoint saves in on_train_epoch_end, AFTER the epoch's scheduler call (`_TrainingEpochLoop.advance`
+        # steps an epoch-interval scheduler behind the last batch, see lightning_epoch_lr): at the epoch-N save the
+        # scheduler has seen its construction-time step plus step(0) .. step(N), so last_epoch = N, _step_count = N + 2,
+        # and `_last_lr` / the optimizer's lr hold closed_form(N) - the rate epoch N+1 will train with.  `lr` overrides
+        # that rate (callers with their own schedule).
+        cur_lr = warmup_cosine_lr(epoch, base_lr=self.opt.lr) if lr is None else lr
         sched = {"warmup_epochs": 15, "max_epochs": 150, "warmup_start_lr": 0.0, "eta_min": 0.0,
-                 "base_lrs": [self.opt.lr], "last_epoch": max(epoch - 1, 0), "_step_count": epoch + 1, "verbose": False,
+                 "base_lrs": [self.opt.lr], "last_epoch": epoch, "_step_count": epoch + 2, "verbose": False,
                  "_get_lr_called_within_step": False, "_last_lr": [cur_lr]}
         return {"epoch": epoch, "global_step": self.opt.steps, "pytorch-lightning_version": "2.0.1",
                 "state_dict": {"net." + k: v.detach().clone() for k, v in self.net.state_dict().items()},

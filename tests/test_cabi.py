@@ -23,8 +23,12 @@ def test_library_exports_every_declared_symbol():
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
     assert _lib.lib.pir_arch() == b"gfx950"
     assert _lib.lib.pir_abi_version() == _lib.ABI_VERSION
-    # the shipped library is the product build: no diagnostic / ablation code paths, no knob that skips work
-    assert _lib.lib.pir_build_flags() == 0
+    # the LOADED library describes its own build (compile-time state, not a constant): no diagnostic macro, the ABI
+    # version of the binding, compiled for gfx950 - a stale or foreign .so behind PIR_LIB fails here
+    flags = _lib.lib.pir_build_flags()
+    assert flags & 1 == 0, "diagnostic build"
+    assert (flags >> 8) & 0xFFFF == _lib.ABI_VERSION
+    assert flags & (1 << 24), "not built with --offload-arch=gfx950"
     assert _lib.lib.pir_tune_set(15, 1) == -22          # round 2's "skip the reductions" experiment knob is gone
     for src in ("gemm.hip", "gemm_x3.hip", "gemm_common.h"):
         text = open(os.path.join(ROOT, "promptir_amd", "csrc", src)).read()
@@ -139,7 +143,7 @@ def test_checkpoint_interchange_with_the_lightning_layout():
     # and back: what this repo writes loads into torch's AdamW
     trainer = DataParallelTrainer.__new__(DataParallelTrainer)
     trainer.net, trainer.opt = net, flat
-    out = trainer.checkpoint(epoch=3, lr=1e-4)
+    out = trainer.checkpoint(epoch=3)
     assert out["pytorch-lightning_version"] == "2.0.1" and "loops" in out and "callbacks" in out and "lr_schedulers" in out
     assert list(out["state_dict"].keys()) == ["net." + k for k in ref_net.state_dict().keys()]
     opt2 = torch.optim.AdamW(list(PromptIR(**kw).parameters()), lr=2e-4)
@@ -148,10 +152,23 @@ def test_checkpoint_interchange_with_the_lightning_layout():
     assert set(st2.keys()) == set(sd.keys())
     for i in sd:
         assert torch.equal(st2[i]["exp_avg"], sd[i]["exp_avg"]) and float(st2[i]["step"]) == 2.0
-    assert opt2.state_dict()["param_groups"][0]["lr"] == 1e-4
-    # scheduler block as Lightning 2.0.1 stores it at the epoch-3 save (before that epoch's scheduler step)
+    # Scheduler block as Lightning 2.0.1 stores it at the epoch-3 save.  Source order restated (Lightning is
+    # not installed here): `_TrainingEpochLoop.advance` ends with
+    #     if self._num_ready_batches_reached():
+    #         self.update_lr_schedulers("epoch", update_plateau_schedulers=False)
+    # and only afterwards `FitLoop.on_advance_end` calls the `on_train_epoch_end` hooks (ModelCheckpoint) and then
+    # `update_lr_schedulers("epoch", update_plateau_schedulers=True)` (plateau schedulers only).  The reference's
+    # `lr_scheduler_step` passes `self.current_epoch` (= 3 here), so the saved scheduler has last_epoch 3, has been
+    # stepped 1 (construction) + 4 times, and `_last_lr` / the optimizer lr are closed_form(3), the rate of epoch 4.
+    from promptir_amd.train import lightning_epoch_lr, warmup_cosine_lr
+    lr3 = warmup_cosine_lr(3)
+    assert opt2.state_dict()["param_groups"][0]["lr"] == lr3
     sch = out["lr_schedulers"][0]
-    assert sch["last_epoch"] == 2 and sch["_step_count"] == 4 and sch["_last_lr"] == [1e-4]
+    assert sch["last_epoch"] == 3 and sch["_step_count"] == 5 and sch["_last_lr"] == [lr3]
+    assert sch["_step_count"] - 2 == sch["last_epoch"]
+    assert lightning_epoch_lr(4) == lr3 and lightning_epoch_lr(0) == 0.0 and lightning_epoch_lr(1) == 0.0
+    e0 = trainer.checkpoint(epoch=0)["lr_schedulers"][0]
+    assert e0["last_epoch"] == 0 and e0["_step_count"] == 2 and e0["_last_lr"] == [0.0]
     assert out["optimizer_states"][0]["param_groups"][0]["initial_lr"] == 2e-4
     # demo.py / evaluate.py read checkpoints through load_checkpoint_file (non-tensor payload, torch >= 2.6)
     for drv in ("demo.py", "evaluate.py"):

@@ -142,19 +142,27 @@ def test_bench_with_two_ranks_sharing_the_gpu():
     out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                 "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
                 "--warmup", "1", "--batch", "4"],
-               {"PIR_SHARE_GPU": "1", "PIR_DIST_BACKEND": "gloo", "PIR_STAGED": "1", "PIR_BENCH_PARAM_CHECK": "1"}, timeout=1500)
+               {"PIR_SHARE_GPU": "1", "PIR_DIST_BACKEND": "gloo", "PIR_BENCH_PARAM_CHECK": "1"}, timeout=1500)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                  # rank 0 only
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["process_group"] == "gloo" and rec["config"]["global_batch"] == 8
     assert rec["scaling"] == "weak" and rec["value"] > 0 and rec["per_gpu_value"] * 2 == pytest.approx(rec["value"], rel=2e-2)
-    assert "overlapped" in rec["config"]["execution"]
+    # the DEFAULT N > 1 step (PIR_STAGED unset): one graph + one all-reduce of the flat gradient ...
+    assert "overlapped" not in rec["config"]["execution"] and rec["config"]["staged_backward"] is False
+    # ... and both exchange modes timed side by side on both batch shapes, so the first multi-GPU run picks the default
+    ab = rec["config"]["staged_ab"]
+    assert ab["default"] == "single"
+    for key in ("single_batch4_ms", "staged_batch4_ms", "single_batch8_ms", "staged_batch8_ms"):
+        assert ab[key] > 0, ab
     assert rec["config5"] is not None and rec["config5"]["global_batch"] == 16
     assert rec["roofline"]["achieved"] > 0 and rec["cpu_baseline"] is None     # cpu_baseline: N=1 only
     # every replica ends with bit-identical parameters (same all-reduced gradient, same AdamW): max |p_rank - p_0| over ranks
     assert rec["config"]["replica_param_spread"] == 0.0
-    assert rec["config"]["world"] == 2 and rec["config"]["staged_backward"] is True
+    assert rec["config"]["world"] == 2
+    ks = rec["config"]["kernel_selection"]
+    assert ks["env"].get("PIR_DIST_BACKEND") == "gloo" and ks["switches"]["USE_X3"] is True and ks["knobs_set"] == {}
 
 
 def test_train_cli_under_an_rccl_process_group(tmp_path):

@@ -664,3 +664,96 @@ def test_l1_and_adamw():
         opt.step()
         ops.adamw_step(pg, (g * step).to(DEV), m, v, step)
     assert float((pg.cpu() - pr.detach()).abs().max()) <= 1e-7
+
+
+def test_l1_part_share_by_value_and_layout_repair():
+    """The part batch's share of the batch travels BY VALUE into both L1 kernels (no device scalar, no ATen multiply);
+    a non-contiguous / permuted view is repaired by the library's own gather kernel (pir_copy_strided4)."""
+    from promptir_amd import ops
+
+    a, b = rnd("a", 4, 3, 16, 24), rnd("b", 4, 3, 16, 24)
+    ar = a.clone().requires_grad_(True)
+    ref = 0.375 * (ar - b).abs().mean()
+    ref.backward()
+    ag = a.to(DEV).requires_grad_(True)
+    loss = ops.l1_loss(ag, b.to(DEV), 0.375)
+    loss.backward(gradient=ops.unit_gradient(DEV))
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-7
+    assert torch.equal(ag.grad.cpu(), ar.grad)
+    # weight 1 is the plain mean bit for bit
+    assert float(ops.l1_loss(a.to(DEV), b.to(DEV))) == float(ops.l1_loss(a.to(DEV), b.to(DEV), 1.0))
+    # channels-last storage / permuted views: same values as the contiguous tensor
+    nhwc = a.permute(0, 2, 3, 1).contiguous().to(DEV).permute(0, 3, 1, 2)      # NCHW view of NHWC storage
+    assert not nhwc.is_contiguous()
+    fixed = ops._planes(nhwc)
+    assert fixed.is_contiguous() and torch.equal(fixed.cpu(), a)
+    assert float(ops.l1_loss(nhwc, b.to(DEV))) == float(ops.l1_loss(a.to(DEV), b.to(DEV)))
+    wt = rnd("w", 5, 3, 1, 1)
+    close(ops.conv1x1_forward(nhwc, wt.to(DEV)), F.conv2d(a, wt))
+    dst = torch.zeros(4 * 3 * 16 * 24, device=DEV)
+    ops.copy_flat(a.to(DEV), dst)
+    assert torch.equal(dst.cpu().view_as(a), a)
+
+
+def test_fork_backward_ownership():
+    """ForkFn.backward: the two gradients are summed by the plane-copy kernel, in place only into a tensor
+    that owns its storage; views (a contiguous channel slice at batch 1), the same tensor arriving twice and a missing
+    gradient are handled without touching a buffer another node may still read."""
+    from promptir_amd import ops
+
+    def run(x, fn):
+        xd = x.to(DEV).requires_grad_(True)
+        a, b = ops.fork(xd)
+        fn(a, b).backward()
+        return xd.grad.cpu()
+
+    x1 = rnd("x", 1, 6, 8, 8)
+    up = rnd("u", 1, 12, 8, 8).to(DEV)
+    # batch 1: the slice of a wider upstream gradient is contiguous AND a view
+    wide = up.clone()
+
+    def via_slice(a, b):
+        cat = ops.CatChannelsFn.apply(a, b)          # its backward hands out channel slices of ONE gradient buffer
+        return (cat * wide).sum()
+
+    g = run(x1, via_slice)
+    assert torch.equal(g, (up[:, :6] + up[:, 6:]).cpu())
+    assert torch.equal(wide, up)                      # nothing upstream was modified
+    # the same gradient tensor for both outputs (a + b)
+    g2 = run(x1, lambda a, b: ((a + b) * up[:, :6]).sum())
+    assert torch.allclose(g2, (2 * up[:, :6]).cpu())
+    # one output unused
+    g3 = run(x1, lambda a, b: (a * up[:, :6]).sum())
+    assert torch.equal(g3, up[:, :6].cpu())
+    # batch 3: a strided slice accumulated into a fresh tensor
+    x3, up3 = rnd("x3", 3, 6, 8, 8), rnd("u3", 3, 12, 8, 8).to(DEV)
+    g4 = run(x3, lambda a, b: (ops.CatChannelsFn.apply(a, b) * up3).sum())
+    assert torch.equal(g4, (up3[:, :6] + up3[:, 6:]).cpu())
+
+
+def test_side_streams_refused_inside_a_multi_stream_capture(monkeypatch):
+    """weight-gradient side streams inside ONE capture that spans several part streams crashed the host
+    in round 3 (never bisected on hardware); the combination now raises.  The capture is simulated - nothing
+    is captured here - so the guard is tested without going near the crash."""
+    from promptir_amd import ops
+
+    s1, s2 = torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)
+    dev = torch.device(DEV)
+    with ops.side_streams(True):
+        with torch.cuda.stream(s1):
+            ops._SideWgrads(dev)                      # not capturing: fine, and clears the capture bookkeeping
+        monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
+        with torch.cuda.stream(s1):
+            ops._SideWgrads(dev)                      # one capturing origin stream: the single-stream graph step
+            ops._SideWgrads(dev)
+        with torch.cuda.stream(s2):
+            with pytest.raises(RuntimeError, match="side streams"):
+                ops._SideWgrads(dev)
+        monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+        with torch.cuda.stream(s2):
+            ops._SideWgrads(dev)                      # the next (non-capturing) use resets it
+    with ops.side_streams(False):
+        monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
+        for s in (s1, s2):
+            with torch.cuda.stream(s):
+                ops._SideWgrads(dev)                  # side streams off: nothing to refuse

@@ -109,7 +109,7 @@ def main():
             print(f"[train] epoch {epoch} lr {lr:.3e} train_loss {running / max(nb, 1):.5f} "
                   f"{nb * opt.batch_size * world / max(dt, 1e-9):.1f} patches/s")
             path = os.path.join(opt.ckpt_dir, f"epoch={epoch}-step={trainer.opt.steps}.ckpt")
-            torch.save(trainer.checkpoint(epoch, lr), path)
+            torch.save(trainer.checkpoint(epoch), path)   # scheduler block: the state AFTER this epoch's scheduler step
         if opt.max_steps and steps >= opt.max_steps:
             break
     if torch.distributed.is_initialized():
