@@ -207,6 +207,52 @@ def modules():
     np.savez_compressed(os.path.join(OUT, "modules.npz"), **store)
 
 
+FULL_GRADS_AT_DEPTH = (   # large tensors whose FULL gradient is pinned at full depth, one per kind of path
+    "latent.7.ffn.project_in.weight",          # 2042 x 384: split-K weight gradient of the 16^2 level
+    "noise_level1.attn.qkv.weight",            # 480 x 160 at 64^2: a noise block (4 heads of 40 channels)
+    "noise_level3.attn.temperature",           # 4 x 1 x 1 (heads of 176 channels)
+    "prompt3.prompt_param",                    # 1 x 5 x 320 x 16 x 16: adjoint of the softmax-weighted prompt mix
+    "refinement.3.attn.qkv.weight",            # 288 x 96 at 128^2: LayerNorm-on-load weight gradient
+    "decoder_level1.0.attn.project_out.weight",   # 96 x 96 at 128^2: dW_proj through the attn @ v fold
+    "encoder_level3.2.ffn.project_out.weight",    # 192 x 510 at 32^2
+    "down2_3.body.0.weight",                   # dense 3x3 weight gradient, 48 x 96 x 3 x 3
+)
+
+
+def full_grad_case():
+    """The run of model_full_128_bwd.npz again (full depth, 2 x 3 x 128 x 128, seed 6, real reference), keeping the FULL
+    gradient of the tensors above - the norm + probe summaries of that file cannot tell two gradients with equal norm
+    and equal projection apart."""
+    PromptIR = _reference("net/model.py").PromptIR
+
+    seed = 6
+    net = PromptIR(decoder=True)
+    load_generated(net, seed)
+    degraded, clean = W.synthetic_pair(2, 128, 128, sigma=[25, 50], seed=seed)
+    loss = torch.nn.L1Loss()(net(torch.from_numpy(degraded)), torch.from_numpy(clean))
+    loss.backward()
+    ref = np.load(os.path.join(OUT, "model_full_128_bwd.npz"))
+    assert abs(float(loss.detach()) - float(ref["loss"])) <= 1e-9, "not the run of model_full_128_bwd.npz"
+    grads = dict(net.named_parameters())
+    out = {"loss": np.array(float(loss.detach()), dtype=np.float64), "seed": np.array(seed)}
+    for name in FULL_GRADS_AT_DEPTH:
+        out["grad/" + name] = grads[name].grad.detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "model_full_128_bwd_fullgrads.npz"), **out)
+    print("full gradients", {k: v.shape for k, v in out.items() if k.startswith("grad/")})
+
+
+def modules_r4():
+    """dec1 / refinement shape of the MDTA block: C = 96 with ONE head, so c = 96 rows per head - the only
+    per-head width above 48 besides the noise blocks.  The 64 x 64 plane puts the block on the attn @ v fold and on the
+    LayerNorm-on-load kernels, as at the network's 128^2 level."""
+    R = _reference("net/model.py")
+
+    store = {}
+    module_case(store, "attn_96_1", R.Attention(96, 1, False), (2, 96, 12, 16), 7)
+    module_case(store, "tblock_96_1", R.TransformerBlock(96, 1, 2.66, False, "WithBias"), (1, 96, 64, 64), 7)
+    np.savez_compressed(os.path.join(OUT, "modules_r4.npz"), **store)
+
+
 def tile_case():
     """Reference model under the restated demo.py tile harness (demo.py itself needs
     `lightning`, which is not installed, so the harness is oracle.tile_eval)."""
@@ -315,6 +361,10 @@ def main():
                        "num_params": sum(p.numel() for p in net.parameters())}, f)
     if want("benchloss"):
         bench_loss_case()
+    if want("modules_r4"):
+        modules_r4()
+    if want("fullgrads"):
+        full_grad_case()
     if want("config3"):   # BASELINE config 3 shapes (128x128, full depth) WITH backward
         model_case("model_full_128_bwd.npz", dict(decoder=True), 2, 128, 128, [25, 50], 6)
         model_case_chunked("model_full_128_b16.npz", dict(decoder=True), 16, 4, 128, 128,

@@ -77,6 +77,17 @@ def test_model_vs_golden(fname, backward):
         if key in z.files:
             ref = z[key]
             assert float(np.abs(g.cpu().numpy() - ref).max()) <= 5e-4 * max(float(np.abs(ref).max()), 1e-3 * scale), name
+    if fname == "model_full_128_bwd.npz":
+        # FULL gradients of large tensors at full depth, element by element: the widest split-K weight
+        # gradient of the 16^2 level, a noise block, the prompt parameters, the LayerNorm-on-load and attn @ v fold paths
+        # of the 128^2 level, a 32^2-level project_out and a dense 3x3 weight gradient
+        zf = util.load_npz("model_full_128_bwd_fullgrads.npz")
+        keys = [k for k in zf.files if k.startswith("grad/")]
+        assert len(keys) >= 8
+        for k in keys:
+            ref, got = zf[k], grads[k[5:]].grad.cpu().numpy()
+            assert ref.shape == got.shape
+            assert float(np.abs(got - ref).max()) <= 5e-4 * float(np.abs(ref).max()), k
 
 
 def test_batch8_inference_vs_oracle():

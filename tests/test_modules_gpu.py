@@ -50,7 +50,7 @@ def _build(tag):
 
 def _tags():
     out = []
-    for f in ("modules.npz", "modules_bias.npz"):   # bias=True modules: net/model.py:88-92,111-113
+    for f in ("modules.npz", "modules_bias.npz", "modules_r4.npz"):   # bias=True modules: net/model.py:88-92,111-113; r4: one head of 96 channels
         z = util.load_npz(f)
         out += sorted({k.split("/")[0] for k in z.files})
     return out
