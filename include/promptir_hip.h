@@ -336,6 +336,14 @@ int pir_l1_loss_grad(const float* restored, const float* clean, const float* dlo
  * promptir_amd/weights.py (keys[2b], keys[2b+1] = the two Box-Muller stream keys of image b). */
 int pir_degrade_gaussian(const float* clean, float* out, const float* sigma, const unsigned long long* keys,
                          long per_image, int B, pir_stream_t stream);
+/* Training patches cut from whole decoded uint8 HWC images on the device: random crop window + augmentation mode chosen
+ * by the host (utils/dataset_utils.py:102-111,140-168, utils/image_utils.py:133-182), applied here as an index map, plus
+ * ToTensor (k / 255) and, for unpaired samples, the sigma noise of utils/degradation_utils.py:21-27 in the uint8 domain.
+ * meta: int64 [B][8] = {byte offset of the clean image in `images`, byte offset of the paired degraded image or -1,
+ * H, W, top, left, mode 0..7, 0}; sigma [B] (ignored for paired samples); keys [2B] as for pir_degrade_gaussian.
+ * Outputs: degraded, clean [B][3][P][P]. */
+int pir_crop_augment_u8(const unsigned char* images, const long* meta, const float* sigma, const unsigned long long* keys,
+                        float* degraded, float* clean, int B, int P, pir_stream_t stream);
 /* y[b][c][n] = x[b][c][n] (+ y if accumulate) for channel-slice copies (torch.cat, net/model.py:341-370) */
 int pir_copy_planes(const float* x, long x_bs, float* y, long y_bs, int accumulate,
                     int B, long plane_floats, pir_stream_t stream);

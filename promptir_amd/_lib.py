@@ -101,6 +101,7 @@ SIGNATURES = {
     "pir_l1_loss_grad": (I, [P, P, P, F, P, L, S]),
     "pir_copy_strided4": (I, [P, L, L, L, L, P, I, I, I, I, S]),
     "pir_degrade_gaussian": (I, [P, P, P, P, L, I, S]),
+    "pir_crop_augment_u8": (I, [P, P, P, P, P, P, I, I, S]),
     "pir_copy_planes": (I, [P, L, P, L, I, I, L, S]),
     "pir_add": (I, [P, P, P, L, S]),
     "pir_bias_add": (I, [P, L, P, I, I, I, S]),

@@ -190,6 +190,55 @@ __global__ __launch_bounds__(256) void degrade_gaussian_kernel(const float* __re
   }
 }
 
+// Training patches cut from whole decoded images ON THE DEVICE (reference: PromptTrainDataset.__getitem__,
+// utils/dataset_utils.py:133-172 - random crop :102-111 / RandomCrop :32-35, random_augmentation utils/image_utils.py:177-182
+// -> data_augmentation :133-160, Degradation.single_degrade utils/degradation_utils.py:21-27, ToTensor).  The host picks
+// the crop window and the augmentation mode (its RNG, like the reference) and ships the uint8 HWC images as they were
+// decoded; this kernel does the index work: out[c][i][j] of sample b is source pixel aug^-1(i, j) of the P x P window.
+// np.rot90 / np.flipud on a square HWC patch m (P x P), out = data_augmentation(m, mode):
+//   0: m[i][j]        1: m[P-1-i][j]      2: m[j][P-1-i]      3: m[j][i]
+//   4: m[P-1-i][P-1-j] 5: m[i][P-1-j]     6: m[P-1-j][i]      7: m[P-1-j][P-1-i]
+// meta[b] = {offset of the clean image, offset of the paired degraded image or -1, H, W, top, left, mode, unused}.
+// Unpaired samples (de_id 0..2) get sigma[b] Gaussian noise in the uint8 domain: uint8(clip(k + n * sigma, 0, 255)).
+__global__ __launch_bounds__(256) void crop_augment_u8_kernel(const unsigned char* __restrict__ images, const long* __restrict__ meta,
+                                                              const float* __restrict__ sigma,
+                                                              const unsigned long long* __restrict__ keys,
+                                                              float* __restrict__ degraded, float* __restrict__ clean, int B, int P) {
+  const long per = 3L * P * P, total = (long)B * per;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(e / per);
+    const long r = e - (long)b * per;
+    const int c = (int)(r / ((long)P * P)), i = (int)((r / P) % P), j = (int)(r % P);
+    const long* m = meta + 8L * b;
+    const long W = m[3], top = m[4], left = m[5];
+    const int mode = (int)m[6], q = P - 1;
+    int si, sj;
+    switch (mode) {
+      case 1: si = q - i; sj = j; break;
+      case 2: si = j; sj = q - i; break;
+      case 3: si = j; sj = i; break;
+      case 4: si = q - i; sj = q - j; break;
+      case 5: si = i; sj = q - j; break;
+      case 6: si = q - j; sj = i; break;
+      case 7: si = q - j; sj = q - i; break;
+      default: si = i; sj = j; break;
+    }
+    const long src = ((top + si) * W + (left + sj)) * 3 + c;
+    const unsigned char k = images[m[0] + src];
+    clean[e] = (float)k / 255.0f;
+    if (m[1] >= 0) {
+      degraded[e] = (float)images[m[1] + src] / 255.0f;
+    } else {
+      const unsigned long long i1 = (unsigned long long)r + 1ULL;
+      const double u1 = (double)u01_splitmix(keys[2 * b], i1), u2 = (double)u01_splitmix(keys[2 * b + 1], i1);
+      const float n = (float)(sqrt(-2.0 * log(1.0 - u1)) * cos(6.283185307179586476925 * u2));
+      double v = (double)k + (double)n * (double)sigma[b];
+      v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+      degraded[e] = (float)(unsigned char)v / 255.0f;
+    }
+  }
+}
+
 inline int grid_for(long total, int cap = 4096) { long g = pir_cdiv(total, 256); if (g < 1) g = 1; return (int)(g < cap ? g : cap); }
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -231,6 +280,14 @@ extern "C" int pir_degrade_gaussian(const float* clean, float* out, const float*
   PIR_CHECK_ARG(clean && out && sigma && keys && per_image > 0 && B > 0);
   hipLaunchKernelGGL(degrade_gaussian_kernel, dim3(grid_for((long)B * per_image)), dim3(256), 0, (hipStream_t)stream,
                      clean, out, sigma, keys, per_image, B);
+  return pir_launch_status();
+}
+
+extern "C" int pir_crop_augment_u8(const unsigned char* images, const long* meta, const float* sigma, const unsigned long long* keys,
+                                   float* degraded, float* clean, int B, int P, pir_stream_t stream) {
+  PIR_CHECK_ARG(images && meta && sigma && keys && degraded && clean && B > 0 && P > 0);
+  hipLaunchKernelGGL(crop_augment_u8_kernel, dim3(grid_for(3L * B * P * P)), dim3(256), 0, (hipStream_t)stream,
+                     images, meta, sigma, keys, degraded, clean, B, P);
   return pir_launch_status();
 }
 

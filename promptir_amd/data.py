@@ -190,3 +190,253 @@ class DevicePrefetcher:
             degrad.record_stream(torch.cuda.current_stream(self.device))
             clean.record_stream(torch.cuda.current_stream(self.device))
             yield degrad, clean
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# All-in-one readers: the reference's folder layout on the host, crop + augmentation
+# + degradation on the device.
+DE_DICT = {'denoise_15': 0, 'denoise_25': 1, 'denoise_50': 2, 'derain': 3, 'dehaze': 4}   # utils/dataset_utils.py:26
+IMG_EXTS = ('jpg', 'JPG', 'png', 'PNG', 'jpeg', 'JPEG', 'bmp', 'BMP')
+
+
+def crop_img(image: np.ndarray, base: int = 64) -> np.ndarray:
+    """utils/image_utils.py:59-64: centre crop to multiples of `base`."""
+    h, w = image.shape[:2]
+    ch, cw = h % base, w % base
+    return image[ch // 2:h - ch + ch // 2, cw // 2:w - cw + cw // 2, :]
+
+
+def rainy_gt_name(rainy_name: str) -> str:
+    """utils/dataset_utils.py:113-115: .../rainy/rain-N.png -> .../gt/norain-N.png"""
+    return rainy_name.split("rainy")[0] + 'gt/norain-' + rainy_name.split('rain-')[-1]
+
+
+def nonhazy_name(hazy_name: str) -> str:
+    """utils/dataset_utils.py:117-122: .../synthetic/<id>_<a>_<b>.jpg -> .../original/<id>.jpg"""
+    dir_name = hazy_name.split("synthetic")[0] + 'original/'
+    name = hazy_name.split('/')[-1].split('_')[0]
+    suffix = '.' + hazy_name.split('.')[-1]
+    return dir_name + name + suffix
+
+
+def aug_source_index(mode: int, i: int, j: int, P: int):
+    """Source (row, column) inside a square P x P patch of output pixel (i, j) of data_augmentation(patch, mode)
+    (utils/image_utils.py:133-160): the index map pir_crop_augment_u8 applies; checked against numpy in the tests."""
+    q = P - 1
+    return {0: (i, j), 1: (q - i, j), 2: (j, q - i), 3: (j, i), 4: (q - i, q - j), 5: (i, q - j), 6: (q - j, i),
+            7: (q - j, q - i)}[mode]
+
+
+class PromptTrainSet(torch.utils.data.Dataset):
+    """The reference's PromptTrainDataset (utils/dataset_utils.py:15-175) over the same folder layout and list files:
+
+        <data_file_dir>noisy/denoise.txt      names of the clean images in <denoise_dir>     (x3 per sigma, :47-73)
+        <data_file_dir>rainy/rainTrain.txt    paths below <derain_dir> of the rainy images    (x120, :88-97); ground
+                                              truth = .../gt/norain-N.* (:113-115)
+        <data_file_dir>hazy/hazy_outside.txt  paths below <dehaze_dir> of the hazy images (:77-86); ground truth =
+                                              .../original/<id>.* (:117-122)
+
+    Same sample list construction (`sample_ids`, merged in the same order), same crop_img(base=16), same random crop
+    window and random_augmentation draw (python `random`: crop :102-111, flag 1..7 utils/image_utils.py:177-182).
+    What differs is WHERE the pixels are touched: __getitem__ returns the decoded uint8 image(s) plus the drawn window
+    and mode; crop, flip / rot90, ToTensor and the sigma noise run on the device (`crop_augment_gpu`)."""
+
+    def __init__(self, data_file_dir: str, denoise_dir: str, derain_dir: str, dehaze_dir: str,
+                 de_type: Sequence[str] = ('denoise_15', 'denoise_25', 'denoise_50', 'derain', 'dehaze'), patch_size: int = 128,
+                 seed: int = 0):
+        from PIL import Image  # noqa: F401  (needed by __getitem__; fail at construction if absent)
+
+        self.patch, self.seed, self.de_type = patch_size, seed, list(de_type)
+        self.sample_ids: List[dict] = []
+        rng = random.Random(seed)
+        clean_ids = []
+        if any(t in self.de_type for t in ('denoise_15', 'denoise_25', 'denoise_50')):
+            wanted = {l.strip() for l in open(data_file_dir + "noisy/denoise.txt")}
+            clean_ids = [denoise_dir + n for n in sorted(os.listdir(denoise_dir)) if n.strip() in wanted]
+            self.num_clean = len(clean_ids)
+        for name, de in (('denoise_15', 0), ('denoise_25', 1), ('denoise_50', 2)):
+            if name in self.de_type:
+                ids = [{"clean_id": x, "de_type": de} for x in clean_ids] * 3
+                rng.shuffle(ids)
+                self.sample_ids += ids
+        if 'derain' in self.de_type:
+            rs = [derain_dir + l.strip() for l in open(data_file_dir + "rainy/rainTrain.txt") if l.strip()]
+            self.sample_ids += [{"clean_id": x, "de_type": 3} for x in rs] * 120
+            self.num_rl = len(rs) * 120
+        if 'dehaze' in self.de_type:
+            hz = [dehaze_dir + l.strip() for l in open(data_file_dir + "hazy/hazy_outside.txt") if l.strip()]
+            self.sample_ids += [{"clean_id": x, "de_type": 4} for x in hz]
+            self.num_hazy = len(hz)
+        if not self.sample_ids:
+            raise FileNotFoundError("no training samples for de_type %s" % (self.de_type,))
+
+    def __len__(self):
+        return len(self.sample_ids)
+
+    @staticmethod
+    def _read(path: str) -> np.ndarray:
+        from PIL import Image
+
+        return crop_img(np.array(Image.open(path).convert('RGB')), base=16)
+
+    def __getitem__(self, idx):
+        sample = self.sample_ids[idx]
+        de_id = sample["de_type"]
+        rng = random.Random((self.seed * 1000003 + idx) & 0xFFFFFFFF)   # per-item stream: worker count does not change the data
+        if de_id < 3:
+            clean = self._read(sample["clean_id"])
+            name = sample["clean_id"].split("/")[-1].split('.')[0]
+            degraded = None
+        else:
+            degraded = self._read(sample["clean_id"])
+            name = rainy_gt_name(sample["clean_id"]) if de_id == 3 else nonhazy_name(sample["clean_id"])
+            clean = self._read(name)
+            if clean.shape != degraded.shape:
+                raise ValueError(f"{sample['clean_id']}: degraded {degraded.shape} and ground truth {clean.shape} differ")
+        h, w = clean.shape[:2]
+        if h < self.patch or w < self.patch:
+            raise ValueError(f"{sample['clean_id']}: {h}x{w} is smaller than the {self.patch} patch")
+        top, left = rng.randint(0, h - self.patch), rng.randint(0, w - self.patch)
+        mode = rng.randint(1, 7)
+        noise_seed = self.seed * 7919 + idx
+        return {"name": name, "de_id": de_id, "clean": np.ascontiguousarray(clean),
+                "degraded": None if degraded is None else np.ascontiguousarray(degraded),
+                "top": top, "left": left, "mode": mode, "noise_seed": noise_seed}
+
+
+def ragged_collate(items):
+    """Whole images of different sizes in ONE uint8 buffer (256-byte aligned pieces) + an int64 [B][8] table
+    {clean offset, degraded offset or -1, H, W, top, left, mode, 0}: what pir_crop_augment_u8 reads."""
+    offs, total = [], 0
+    for it in items:
+        for key in ("clean", "degraded"):
+            a = it[key]
+            if a is None:
+                offs.append(-1)
+                continue
+            offs.append(total)
+            total += (a.size + 255) // 256 * 256
+    buf = torch.empty(max(total, 256), dtype=torch.uint8)
+    view = buf.numpy()
+    meta = torch.zeros((len(items), 8), dtype=torch.int64)
+    for b, it in enumerate(items):
+        for k, key in enumerate(("clean", "degraded")):
+            a, o = it[key], offs[2 * b + k]
+            if a is not None:
+                view[o:o + a.size] = a.reshape(-1)
+        h, w = it["clean"].shape[:2]
+        meta[b] = torch.tensor([offs[2 * b], offs[2 * b + 1], h, w, it["top"], it["left"], it["mode"], 0])
+    de = torch.tensor([it["de_id"] for it in items], dtype=torch.int64)
+    seeds = torch.tensor([it["noise_seed"] for it in items], dtype=torch.int64)
+    return {"images": buf, "meta": meta, "de_id": de, "noise_seed": seeds, "names": [it["name"] for it in items]}
+
+
+def crop_augment_gpu(images: torch.Tensor, meta: torch.Tensor, de_ids, noise_seeds, patch: int, out=None):
+    """(degraded, clean) [B,3,P,P] on the device from a ragged uint8 batch (pir_crop_augment_u8).  `out`: a pair of
+    preallocated tensors (e.g. the trainer's static graph inputs) to write into."""
+    from .ops import _stream, check, lib
+
+    if not images.is_cuda or images.dtype != torch.uint8 or meta.dtype != torch.int64:
+        raise RuntimeError("crop_augment_gpu: uint8 images and int64 meta on a ROCm device expected (no CPU fallback)")
+    b = meta.shape[0]
+    dev = images.device
+    keys, sig = [], []
+    for i in range(b):
+        s = int(noise_seeds[i])
+        keys += [_stream_key("noise#bm1", s), _stream_key("noise#bm2", s)]
+        sig.append(SIGMA_OF_DE_ID.get(int(de_ids[i]), 0.0))
+    keys_t = torch.tensor(np.array(keys, dtype=np.uint64).view(np.int64), device=dev)
+    sig_t = torch.tensor(sig, dtype=torch.float32, device=dev)
+    meta_d = meta.to(dev, non_blocking=True)
+    if out is None:
+        degraded = torch.empty((b, 3, patch, patch), dtype=torch.float32, device=dev)
+        clean = torch.empty_like(degraded)
+    else:
+        degraded, clean = out
+    check(lib.pir_crop_augment_u8(images.data_ptr(), meta_d.data_ptr(), sig_t.data_ptr(), keys_t.data_ptr(),
+                                  degraded.data_ptr(), clean.data_ptr(), b, patch, _stream()), "pir_crop_augment_u8")
+    return degraded, clean
+
+
+def crop_augment_host(item: dict, patch: int):
+    """Host statement of the same item for the tests: numpy crop + utils/image_utils.py data_augmentation + ToTensor,
+    and for unpaired samples the uint8-domain noise with the counter generator (element order CHW, as the device)."""
+    t, l = item["top"], item["left"]
+    cl = augment(item["clean"][t:t + patch, l:l + patch], item["mode"])
+    clean = np.ascontiguousarray(cl.transpose(2, 0, 1))
+    if item["degraded"] is not None:
+        dg = augment(item["degraded"][t:t + patch, l:l + patch], item["mode"])
+        deg = np.ascontiguousarray(dg.transpose(2, 0, 1))
+    else:
+        noise = W.normal01("noise", clean.size, item["noise_seed"]).reshape(clean.shape).astype(np.float64)
+        deg = np.clip(clean.astype(np.float64) + noise * SIGMA_OF_DE_ID[item["de_id"]], 0, 255).astype(np.uint8)
+    return deg.astype(np.float32) / np.float32(255.0), clean.astype(np.float32) / np.float32(255.0)
+
+
+class RaggedDevicePrefetcher:
+    """DevicePrefetcher for PromptTrainSet batches: the ragged uint8 buffer and its table go host -> device on a side
+    stream from pinned memory, then ONE kernel cuts, augments, converts and degrades the patches there - one batch
+    ahead of the step that consumes it."""
+
+    def __init__(self, loader, device, patch: int):
+        self.loader, self.device, self.patch = loader, device, patch
+        self.stream = torch.cuda.Stream(device)
+
+    def _stage(self, batch):
+        with torch.cuda.stream(self.stream):
+            images = batch["images"].to(self.device, non_blocking=True)
+            degrad, clean = crop_augment_gpu(images, batch["meta"], batch["de_id"].tolist(), batch["noise_seed"].tolist(),
+                                             self.patch)
+            ready = torch.cuda.Event()
+            ready.record(self.stream)
+        return degrad, clean, ready, images
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            nxt = self._stage(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            degrad, clean, ready, images = nxt
+            try:
+                nxt = self._stage(next(it))
+            except StopIteration:
+                nxt = None
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ready)
+            degrad.record_stream(cur)
+            clean.record_stream(cur)
+            del images
+            yield degrad, clean
+
+
+class DerainDehazeTestSet:
+    """utils/dataset_utils.py:228-301 DerainDehazeDataset: <path>input/* with ground truth <path>target/<same name>
+    (derain) or <path>target/<id>.png for input <id>_*.* (dehaze); crop_img(base=16); items (name, degraded, clean)
+    uint8 HWC."""
+
+    def __init__(self, derain_path: str, dehaze_path: str, task: str = "derain"):
+        self.derain_path, self.dehaze_path = derain_path, dehaze_path
+        self.set_dataset(task)
+
+    def set_dataset(self, task: str):
+        self.task_idx = {'derain': 0, 'dehaze': 1}[task]
+        root = (self.derain_path if self.task_idx == 0 else self.dehaze_path) + 'input/'
+        self.ids = [root + n for n in sorted(os.listdir(root))]
+
+    def gt_path(self, degraded_name: str) -> str:
+        if self.task_idx == 0:
+            return degraded_name.replace("input", "target")
+        return degraded_name.split("input")[0] + 'target/' + degraded_name.split('/')[-1].split('_')[0] + '.png'
+
+    def __len__(self):
+        return len(self.ids)
+
+    def __getitem__(self, idx):
+        from PIL import Image
+
+        p = self.ids[idx]
+        deg = crop_img(np.array(Image.open(p).convert('RGB')), base=16)
+        clean = crop_img(np.array(Image.open(self.gt_path(p)).convert('RGB')), base=16)
+        return p.split('/')[-1][:-4], deg, clean

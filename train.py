@@ -7,7 +7,8 @@
 Same knobs as the reference's options.py (:3-39) where they apply; same recipe as train.py:28-56 — L1 loss,
 AdamW(lr 2e-4, torch defaults), LinearWarmupCosineAnnealingLR(15, 150) stepped per EPOCH with the closed
 form (so lr == 0 during epoch 0, as in the reference), one checkpoint per epoch whose `state_dict` keys are
-`net.<PromptIR key>` like Lightning's.  Data: --denoise_dir if it exists, else a deterministic synthetic set.
+`net.<PromptIR key>` like Lightning's.  Data: the reference's all-in-one folder layout (--data_file_dir with
+--denoise_dir / --derain_dir / --dehaze_dir) if present, else --denoise_dir alone, else a deterministic synthetic set.
 """
 import argparse
 import os
@@ -30,7 +31,10 @@ def parse():
     p.add_argument('--de_type', nargs='+', default=['denoise_15', 'denoise_25', 'denoise_50', 'derain', 'dehaze'])
     p.add_argument('--patch_size', type=int, default=128)
     p.add_argument('--num_workers', type=int, default=16)
+    p.add_argument('--data_file_dir', type=str, default='data_dir/', help='list files: noisy/denoise.txt, rainy/rainTrain.txt, hazy/hazy_outside.txt')
     p.add_argument('--denoise_dir', type=str, default='data/Train/Denoise/')
+    p.add_argument('--derain_dir', type=str, default='data/Train/Derain/')
+    p.add_argument('--dehaze_dir', type=str, default='data/Train/Dehaze/')
     p.add_argument('--ckpt_dir', type=str, default='train_ckpt')
     p.add_argument('--num_gpus', type=int, default=1)
     p.add_argument('--synthetic', type=int, default=0, help='use N synthetic samples per epoch (default when no data dir)')
@@ -57,8 +61,13 @@ def main():
         raise SystemExit("train.py needs a ROCm device (no CPU fallback)")
     device = torch.device("cuda", local)
     de_ids = [i for i, n in enumerate(['denoise_15', 'denoise_25', 'denoise_50']) if n in opt.de_type]
-    gpu_degrade = False
-    if os.path.isdir(opt.denoise_dir) and not opt.synthetic:
+    gpu_degrade, ragged = False, False
+    if os.path.isdir(opt.data_file_dir) and not opt.synthetic:
+        # the reference's all-in-one layout (options.py:20-27, utils/dataset_utils.py:15-175): whole decoded images go to
+        # the device, where ONE kernel crops, augments, converts and degrades them (RaggedDevicePrefetcher)
+        dataset = D.PromptTrainSet(opt.data_file_dir, opt.denoise_dir, opt.derain_dir, opt.dehaze_dir, opt.de_type, opt.patch_size)
+        ragged = True
+    elif os.path.isdir(opt.denoise_dir) and not opt.synthetic:
         dataset = D.DenoiseFolderTrainSet(opt.denoise_dir, opt.patch_size, de_ids or [0, 1, 2])
     elif opt.gpu_degrade:
         dataset = D.CleanPatchSet(opt.synthetic or 64 * opt.batch_size * world, opt.patch_size, de_ids or [0, 1, 2])
@@ -93,10 +102,11 @@ def main():
         # stream while the current step runs, and the logged loss is accumulated on the device: no host sync per step.
         loader = torch.utils.data.DataLoader(dataset, batch_size=opt.batch_size, sampler=idx, drop_last=True,
                                              num_workers=min(opt.num_workers, os.cpu_count() or 1), pin_memory=True,
-                                             persistent_workers=False)
+                                             persistent_workers=False, collate_fn=D.ragged_collate if ragged else None)
         t0, nb = time.time(), 0
         running = torch.zeros((), dtype=torch.float32, device=device)
-        for degrad, clean in D.DevicePrefetcher(loader, device, gpu_degrade):
+        batches = D.RaggedDevicePrefetcher(loader, device, opt.patch_size) if ragged else D.DevicePrefetcher(loader, device, gpu_degrade)
+        for degrad, clean in batches:
             loss = trainer.train_step(degrad, clean, lr=lr)
             ops.add_(running, loss)
             nb += 1
