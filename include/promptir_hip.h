@@ -369,6 +369,16 @@ int pir_gelu_gate_bwd(const float* t, long t_bs, const float* dg, long dg_bs, fl
 /* out[j] = alpha * sum_{s<S} parts[s*stride + j] (+ out[j] if accumulate) */
 int pir_reduce_partials(const float* parts, long stride, int S, float alpha, int accumulate,
                         float* out, long count, pir_stream_t stream);
+/* Deferred, batched second stages (reduce_batch.hip).  Every split reduction of the path that feeds a PARAMETER gradient
+ * (split-K weight gradients, LayerNorm dweight / dbias, depthwise weight gradients, dtemperature rows) is a ~5 us launch
+ * nothing waits for before the optimiser.  pir_reduce_defer(stream, 1): from now on the library QUEUES such a reduction
+ * requested on `stream` instead of launching it; pir_reduce_defer(stream, 0) ends the scope (queued work stays queued);
+ * pir_reduce_flush(stream) runs everything queued, up to 16 reductions per launch, with results bit-identical to the
+ * immediate form.  The caller keeps the partial buffers (the `ws` it passed) alive and untouched until the flush.
+ * pir_reduce_pending: number of queued reductions (host-only query). */
+int pir_reduce_defer(pir_stream_t stream, int on);
+int pir_reduce_flush(pir_stream_t stream);
+int pir_reduce_pending(pir_stream_t stream);
 /* torch.optim.AdamW step (train.py:53: lr 2e-4, betas .9/.999, eps 1e-8, weight_decay 1e-2),
  * over a flat parameter / gradient / moment buffer.  `step` is the 1-based step count. */
 int pir_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long count,

@@ -109,6 +109,9 @@ SIGNATURES = {
     "pir_gelu_gate": (I, [P, L, P, L, I, I, I, S]),
     "pir_gelu_gate_bwd": (I, [P, L, P, L, P, L, I, I, I, S]),
     "pir_reduce_partials": (I, [P, L, I, F, I, P, L, S]),
+    "pir_reduce_defer": (I, [S, I]),
+    "pir_reduce_flush": (I, [S]),
+    "pir_reduce_pending": (I, [S]),
     "pir_ln_conv1x1_fwd": (I, [P, L, P, P, P, I, P, L, P, P, I, I, I, I, S]),
     "pir_conv1x1_wgrad_ln": (I, [P, L, P, L, P, P, P, P, P, P, Z, I, I, I, I, S]),
     "pir_conv1x1_dgrad_ln_bwd": (I, [P, L, P, I, I, P, L, P, P, P, P, L, P, L, P, P, P, Z, I, I, I, S]),

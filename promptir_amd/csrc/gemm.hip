@@ -782,43 +782,11 @@ void gemm_nt_x3_kernel(NTParams p) {
     }
 }
 
-// G[o][i][j] (strided) = alpha * sum_s ws[s][o][i][j]  (+ G).  64 consecutive elements x GR split
-// groups per block; every thread sums its groups' splits with independent loads in flight, the
-// groups are combined through LDS in a fixed order (deterministic).
-template <int GR>
-__global__ __launch_bounds__(64 * GR) void nt_reduce_kernel(const float* __restrict__ ws, int splits, long per_split,
-                                                            int M1, int M2, float* __restrict__ G, long g_so,
-                                                            long g_si, long g_sj, float alpha, int accumulate,
-                                                            long g_st = 0) {
-  __shared__ float red[GR][64];
-  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const long e = blockIdx.x * 64L + lane;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (e < per_split) {
-    int k = grp;
-    for (; k + 3 * GR < splits; k += 4 * GR) {
-      s0 += ws[(long)k * per_split + e];
-      s1 += ws[(long)(k + GR) * per_split + e];
-      s2 += ws[(long)(k + 2 * GR) * per_split + e];
-      s3 += ws[(long)(k + 3 * GR) * per_split + e];
-    }
-    for (; k < splits; k += GR) s0 += ws[(long)k * per_split + e];
-  }
-  red[grp][lane] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (grp == 0 && e < per_split) {
-    float s = 0.f;
-#pragma unroll
-    for (int q = 0; q < GR; ++q) s += red[q][lane];
-    const long o = e / ((long)M1 * M2);
-    const long ij = e % ((long)M1 * M2);
-    const long i = ij / M2, j = ij % M2;
-    // g_st != 0: j enumerates (channel, tap) pairs, channel stride g_sj and tap stride g_st
-    float* dst = g_st ? G + o * g_so + i * g_si + (j / 9) * g_sj + (j % 9) * g_st : G + o * g_so + i * g_si + j * g_sj;
-    const float v = alpha * s;
-    *dst = accumulate ? *dst + v : v;
-  }
-}
+// second stage of every split-K product: reduce_batch.hip (launched at once, or queued inside a deferral scope)
+}  // namespace
+int pir_nt_reduce_submit(const float* ws, int splits, long O, int M1, int M2, float* G, long g_so, long g_si, long g_sj, long g_st,
+                         float alpha, int accumulate, hipStream_t s);
+namespace {
 
 // tile configurations of gemm_nt: 0: 64x64 (4 k-slices)  1: 128x64 (2 k-slices)  2: 128x96 (2 k-slices)  3: 128x128
 struct NTPlan {
@@ -931,15 +899,7 @@ int launch_nt(NTParams& p, size_t ws_floats, int tap_sign, long g_st, hipStream_
   }
   int st = pir_launch_status();
   if (st) return st;
-  const long per_split = (long)O * g.M1 * g.M2;
-  const unsigned blocks = (unsigned)pir_cdiv(per_split, 64);
-  if (pl.splits >= 64)
-    hipLaunchKernelGGL((nt_reduce_kernel<16>), dim3(blocks), dim3(1024), 0, s, g.ws, pl.splits, per_split, g.M1, g.M2,
-                       g.G, g.g_so, g.g_si, g.g_sj, g.alpha, g.accumulate, g_st);
-  else
-    hipLaunchKernelGGL((nt_reduce_kernel<4>), dim3(blocks), dim3(256), 0, s, g.ws, pl.splits, per_split, g.M1, g.M2,
-                       g.G, g.g_so, g.g_si, g.g_sj, g.alpha, g.accumulate, g_st);
-  return pir_launch_status();
+  return pir_nt_reduce_submit(g.ws, pl.splits, O, g.M1, g.M2, g.G, g.g_so, g.g_si, g.g_sj, g_st, g.alpha, g.accumulate, s);
 }
 
 }  // namespace
@@ -947,15 +907,7 @@ int launch_nt(NTParams& p, size_t ws_floats, int tap_sign, long g_st, hipStream_
 // second stage of a split-K product whose partials another kernel wrote (gemm_ntx.hip)
 int pir_nt_reduce_launch(const float* ws, int splits, int M1, int M2, float* G, long g_so, long g_si, long g_sj, float alpha,
                          int accumulate, hipStream_t s) {
-  const long per_split = (long)M1 * M2;
-  const unsigned blocks = (unsigned)pir_cdiv(per_split, 64);
-  if (splits >= 64)
-    hipLaunchKernelGGL((nt_reduce_kernel<16>), dim3(blocks), dim3(1024), 0, s, ws, splits, per_split, M1, M2, G, g_so, g_si, g_sj,
-                       alpha, accumulate, 0L);
-  else
-    hipLaunchKernelGGL((nt_reduce_kernel<4>), dim3(blocks), dim3(256), 0, s, ws, splits, per_split, M1, M2, G, g_so, g_si, g_sj,
-                       alpha, accumulate, 0L);
-  return pir_launch_status();
+  return pir_nt_reduce_submit(ws, splits, 1, M1, M2, G, g_so, g_si, g_sj, 0L, alpha, accumulate, s);
 }
 
 int pir_gdfn_wave_tune(int knob, int value);   // gdfn_bwd.hip

@@ -75,74 +75,6 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, c
     out[i] = a[i] + b[i];
 }
 
-// out[j] = alpha * sum_s parts[s*stride + j]: 64 outputs x GR split-groups per workgroup; each thread sums
-// its group's rows with four independent accumulators (loads in flight), groups are combined through LDS
-// in a fixed order (deterministic).
-template <int GR>
-__global__ __launch_bounds__(64 * GR) void reduce_partials_kernel(const float* __restrict__ parts, long stride, int S,
-                                                                  float alpha, int accumulate, float* __restrict__ out,
-                                                                  long count, float* __restrict__ out2 = nullptr,
-                                                                  long split = 0) {
-  __shared__ float red[GR][64];
-  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const long j = blockIdx.x * 64L + lane;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (j < count) {
-    int k = grp;
-    for (; k + 3 * GR < S; k += 4 * GR) {
-      s0 += parts[(long)k * stride + j];
-      s1 += parts[(long)(k + GR) * stride + j];
-      s2 += parts[(long)(k + 2 * GR) * stride + j];
-      s3 += parts[(long)(k + 3 * GR) * stride + j];
-    }
-    for (; k < S; k += GR) s0 += parts[(long)k * stride + j];
-  }
-  red[grp][lane] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (grp == 0 && j < count) {
-    float s = 0.f;
-#pragma unroll
-    for (int q = 0; q < GR; ++q) s += red[q][lane];
-    s *= alpha;
-    float* dst = (out2 && j >= split) ? out2 + (j - split) : out + j;   // two destinations: columns [0, split) and the rest
-    *dst = accumulate ? *dst + s : s;
-  }
-}
-
-// Few outputs, many rows (LayerNorm dweight / dbias, depthwise weight gradients: 48..1872 outputs from up to 2048
-// partial rows): 16 outputs x 64 row groups per workgroup, so that each thread walks S / 64 rows instead of S / 16 and
-// 4x as many workgroups share the work (with 64 outputs per workgroup two CUs summed a whole LayerNorm gradient, a
-// chain of ~32 dependent load rounds).  Fixed summation order.
-__global__ __launch_bounds__(1024) void reduce_partials_narrow_kernel(const float* __restrict__ parts, long stride, int S,
-                                                                      float alpha, int accumulate, float* __restrict__ out,
-                                                                      long count, float* __restrict__ out2 = nullptr,
-                                                                      long split = 0) {
-  __shared__ float red[64][17];
-  const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
-  const long j = blockIdx.x * 16L + col;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (j < count) {
-    int k = grp;
-    for (; k + 192 < S; k += 256) {
-      s0 += parts[(long)k * stride + j];
-      s1 += parts[(long)(k + 64) * stride + j];
-      s2 += parts[(long)(k + 128) * stride + j];
-      s3 += parts[(long)(k + 192) * stride + j];
-    }
-    for (; k < S; k += 64) s0 += parts[(long)k * stride + j];
-  }
-  red[grp][col] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (grp == 0 && j < count) {
-    float s = 0.f;
-#pragma unroll
-    for (int q = 0; q < 64; ++q) s += red[q][col];
-    s *= alpha;
-    float* dst = (out2 && j >= split) ? out2 + (j - split) : out + j;
-    *dst = accumulate ? *dst + s : s;
-  }
-}
-
 // torch.optim.AdamW single-tensor update, same operation order:
 //   p *= 1 - lr*wd; m = lerp(m, g, 1-b1); v = b2*v + (1-b2) g^2;
 //   p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
@@ -305,29 +237,6 @@ extern "C" int pir_add(const float* a, const float* b, float* out, long count, p
   PIR_CHECK_ARG(a && b && out && count > 0);
   hipLaunchKernelGGL(add_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, a, b, out, count);
   return pir_launch_status();
-}
-
-// columns [0, split) of the partial rows go to `out`, columns [split, count) to `out2` (one launch for LayerNorm's
-// dweight and dbias, whose partial rows are [2][C]); out2 == nullptr: everything to `out`
-int pir_reduce_partials_to2(const float* parts, long stride, int S, float alpha, int accumulate, float* out, float* out2,
-                            long split, long count, pir_stream_t stream) {
-  PIR_CHECK_ARG(parts && out && S > 0 && count > 0);
-  const unsigned blocks = (unsigned)pir_cdiv(count, 64);
-  if (S >= 256 && count <= 4096)
-    hipLaunchKernelGGL(reduce_partials_narrow_kernel, dim3((unsigned)pir_cdiv(count, 16)), dim3(1024), 0, (hipStream_t)stream,
-                       parts, stride, S, alpha, accumulate, out, count, out2, split);
-  else if (S >= 64)
-    hipLaunchKernelGGL((reduce_partials_kernel<16>), dim3(blocks), dim3(1024), 0, (hipStream_t)stream,
-                       parts, stride, S, alpha, accumulate, out, count, out2, split);
-  else
-    hipLaunchKernelGGL((reduce_partials_kernel<4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       parts, stride, S, alpha, accumulate, out, count, out2, split);
-  return pir_launch_status();
-}
-
-extern "C" int pir_reduce_partials(const float* parts, long stride, int S, float alpha, int accumulate,
-                                   float* out, long count, pir_stream_t stream) {
-  return pir_reduce_partials_to2(parts, stride, S, alpha, accumulate, out, nullptr, 0, count, stream);
 }
 
 extern "C" int pir_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long count,

@@ -64,9 +64,9 @@ class Conv3x3(_ConvParams):
     def __init__(self, in_channels, out_channels, bias=False):
         super().__init__(in_channels, out_channels, 3, 1, bias)
 
-    def forward(self, x, residual: Optional[torch.Tensor] = None):
+    def forward(self, x, residual: Optional[torch.Tensor] = None, out: Optional["ops.OutSlot"] = None):
         _check_channels(x, self.in_channels, "Conv3x3")
-        return self._add_bias(ops.Conv3x3Fn.apply(x, self.weight, residual))
+        return self._add_bias(ops.Conv3x3Fn.apply(x, self.weight, residual, out))
 
 
 class DepthwiseConv3x3(_ConvParams):
@@ -86,8 +86,8 @@ class PixelUnshuffle2(nn.Module):
 
 
 class PixelShuffle2(nn.Module):
-    def forward(self, x):
-        return ops.PixelShuffleFn.apply(x)
+    def forward(self, x, out: Optional["ops.OutSlot"] = None):
+        return ops.PixelShuffleFn.apply(x, out)
 
 
 ##########################################################################
@@ -183,8 +183,8 @@ class Upsample(nn.Module):
         super().__init__()
         self.body = nn.Sequential(Conv3x3(n_feat, n_feat * 2), PixelShuffle2())
 
-    def forward(self, x):
-        return self.body(x)
+    def forward(self, x, out: Optional["ops.OutSlot"] = None):
+        return self.body[1](self.body[0](x), out)
 
 
 ##########################################################################
@@ -197,19 +197,19 @@ class TransformerBlock(nn.Module):
         self.norm2 = LayerNorm(dim, LayerNorm_type)
         self.ffn = FeedForward(dim, ffn_expansion_factor, bias)
 
-    def forward(self, x):
+    def forward(self, x, out: Optional["ops.OutSlot"] = None):
         _check_channels(x, self.norm1.body.normalized_shape[0], "TransformerBlock")
         a, f = self.attn, self.ffn
         if a.qkv.bias is not None:   # bias=True: composed from the per-op nodes (each conv followed by its bias add)
             x = a(self.norm1(x), residual=x)
-            return f(self.norm2(x), residual=x)
+            return f(self.norm2(x), residual=x)   # (`out` unused: the concat then copies, ops.CatChannelsFn)
         # one autograd node per block; residual adds live in the project_out epilogues (forward) and in
         # the LayerNorm-backward kernel (backward).  Equivalent to
         #   x = self.attn(self.norm1(x), residual=x); x = self.ffn(self.norm2(x), residual=x)
         return ops.TransformerBlockFn.apply(
             x, self.norm1.body.weight, getattr(self.norm1.body, "bias", None), a.temperature, a.qkv.weight,
             a.qkv_dwconv.weight, a.project_out.weight, self.norm2.body.weight, getattr(self.norm2.body, "bias", None),
-            f.project_in.weight, f.dwconv.weight, f.project_out.weight, a.num_heads, not torch.is_grad_enabled())
+            f.project_in.weight, f.dwconv.weight, f.project_out.weight, a.num_heads, not torch.is_grad_enabled(), out)
 
 
 ##########################################################################
@@ -245,14 +245,26 @@ class PromptGenBlock(nn.Module):
         self.linear_layer = _LinearParams(lin_dim, prompt_len)
         self.conv3x3 = Conv3x3(prompt_dim, prompt_dim)
 
-    def forward(self, x):
+    def forward(self, x, out: Optional["ops.OutSlot"] = None):
         _check_channels(x, self.linear_layer.in_features, "PromptGenBlock")
         prompt = ops.PromptGenFn.apply(x, self.prompt_param, self.linear_layer.weight, self.linear_layer.bias)
-        return self.conv3x3(prompt)
+        return self.conv3x3(prompt, out=out)
 
 
 def _cat(a, b):
     return ops.CatChannelsFn.apply(a, b)
+
+
+def _run_stage(stage: nn.Sequential, x, out: Optional["ops.OutSlot"] = None):
+    """nn.Sequential of TransformerBlocks; the last block may write its output into a concat buffer slot."""
+    n = len(stage)
+    for i, blk in enumerate(stage):
+        x = blk(x, out if i == n - 1 else None)
+    return x
+
+
+def _slot(buf, c0, c):
+    return ops.OutSlot(buf, c0, c) if buf is not None else None
 
 
 ##########################################################################
@@ -340,14 +352,30 @@ class PromptIR(nn.Module):
     def encode_levels(self, inp_img):
         """patch_embed, encoder levels 1-3 and the three downsamplings -> (enc1, enc2, enc3, latent input)."""
         inp_enc_level1 = self.patch_embed(inp_img)
+        # The six torch.cat of the decoder (net/model.py:341-370) cost nothing here: each concat buffer is allocated
+        # BEFORE its first producer runs and both producers write their halves in place (the last block of an encoder
+        # level / the latent / a decoder level through its project_out epilogue, the upsampling through its pixel
+        # shuffle, the prompt blocks through their 3x3 convolution); ops.CatChannelsFn then finds the two halves
+        # adjacent in a registered buffer and returns the buffer.  A skip tensor is the second half of
+        # [upsampled | skip]; latent / decoder outputs are the first half of [features | prompt].
+        b, _, h, w = inp_img.shape
+        dim = self.patch_embed.proj.out_channels
+        place = ops.CAT_INPLACE and self.decoder_level1[0].attn.qkv.bias is None
+        c6 = ops.new_cat_buffer(inp_img, 2 * dim, h, w) if place else None                # [up2_1 | enc1]
+        c4 = ops.new_cat_buffer(inp_img, 4 * dim, h // 2, w // 2) if place else None      # [up3_2 | enc2]
+        c2 = ops.new_cat_buffer(inp_img, 6 * dim, h // 4, w // 4) if place else None      # [up4_3 | enc3]
         # every encoder output feeds the next level AND the decoder's skip connection: ops.fork sums the two
         # gradients with the library's own kernel
-        out_enc_level1, skip1 = ops.fork(self.encoder_level1(inp_enc_level1))
-        out_enc_level2, skip2 = ops.fork(self.encoder_level2(self.down1_2(out_enc_level1)))
-        out_enc_level3, skip3 = ops.fork(self.encoder_level3(self.down2_3(out_enc_level2)))
+        out_enc_level1, skip1 = ops.fork(_run_stage(self.encoder_level1, inp_enc_level1, _slot(c6, dim, dim)))
+        out_enc_level2, skip2 = ops.fork(_run_stage(self.encoder_level2, self.down1_2(out_enc_level1), _slot(c4, 2 * dim, 2 * dim)))
+        out_enc_level3, skip3 = ops.fork(_run_stage(self.encoder_level3, self.down2_3(out_enc_level2), _slot(c2, 2 * dim, 4 * dim)))
         return skip1, skip2, skip3, self.down3_4(out_enc_level3)
 
     def run_latent(self, inp_latent):
+        if self.decoder and ops.CAT_INPLACE and self.latent[0].attn.qkv.bias is None:
+            b, c, h, w = inp_latent.shape
+            c1 = ops.new_cat_buffer(inp_latent, c + self.prompt3.conv3x3.out_channels, h, w)   # [latent | prompt3]
+            return _run_stage(self.latent, inp_latent, _slot(c1, 0, c))
         return self.latent(inp_latent)
 
     def encode(self, inp_img):
@@ -355,26 +383,43 @@ class PromptIR(nn.Module):
         return self.run_latent(inp_latent), out_enc_level3, out_enc_level2, out_enc_level1
 
     def decode(self, inp_img, latent, out_enc_level3, out_enc_level2, out_enc_level1):
+        def second_half(first):      # slot behind `first` in the registered buffer it was produced into
+            buf = ops.cat_buffer_of(first) if ops.CAT_INPLACE else None
+            return _slot(buf, first.shape[1], buf.shape[1] - first.shape[1]) if buf is not None else None
+
+        def first_half(skip):        # slot in front of a skip tensor
+            buf = ops.cat_buffer_of(skip) if ops.CAT_INPLACE else None
+            return _slot(buf, 0, buf.shape[1] - skip.shape[1]) if buf is not None else None
+
+        def prompt_buffer(x, prompt):   # [decoder features | prompt] allocated before the decoder level runs
+            if not (self.decoder and ops.CAT_INPLACE and self.decoder_level1[0].attn.qkv.bias is None):
+                return None
+            return ops.new_cat_buffer(x, prompt.linear_layer.in_features + prompt.conv3x3.out_channels, x.shape[2], x.shape[3])
+
         if self.decoder:
             latent, to_prompt = ops.fork(latent)
-            latent = _cat(latent, self.prompt3(to_prompt))
+            latent = _cat(latent, self.prompt3(to_prompt, out=second_half(latent)))
             latent = self.reduce_noise_level3(self.noise_level3(latent))
 
-        inp_dec_level3 = _cat(self.up4_3(latent), out_enc_level3)
-        out_dec_level3 = self.decoder_level3(self.reduce_chan_level3(inp_dec_level3))
+        inp_dec_level3 = _cat(self.up4_3(latent, out=first_half(out_enc_level3)), out_enc_level3)
+        x3 = self.reduce_chan_level3(inp_dec_level3)
+        c3 = prompt_buffer(x3, self.prompt2) if self.decoder else None
+        out_dec_level3 = _run_stage(self.decoder_level3, x3, _slot(c3, 0, x3.shape[1]))
         if self.decoder:
             out_dec_level3, to_prompt = ops.fork(out_dec_level3)
-            out_dec_level3 = _cat(out_dec_level3, self.prompt2(to_prompt))
+            out_dec_level3 = _cat(out_dec_level3, self.prompt2(to_prompt, out=second_half(out_dec_level3)))
             out_dec_level3 = self.reduce_noise_level2(self.noise_level2(out_dec_level3))
 
-        inp_dec_level2 = _cat(self.up3_2(out_dec_level3), out_enc_level2)
-        out_dec_level2 = self.decoder_level2(self.reduce_chan_level2(inp_dec_level2))
+        inp_dec_level2 = _cat(self.up3_2(out_dec_level3, out=first_half(out_enc_level2)), out_enc_level2)
+        x2 = self.reduce_chan_level2(inp_dec_level2)
+        c5 = prompt_buffer(x2, self.prompt1) if self.decoder else None
+        out_dec_level2 = _run_stage(self.decoder_level2, x2, _slot(c5, 0, x2.shape[1]))
         if self.decoder:
             out_dec_level2, to_prompt = ops.fork(out_dec_level2)
-            out_dec_level2 = _cat(out_dec_level2, self.prompt1(to_prompt))
+            out_dec_level2 = _cat(out_dec_level2, self.prompt1(to_prompt, out=second_half(out_dec_level2)))
             out_dec_level2 = self.reduce_noise_level1(self.noise_level1(out_dec_level2))
 
-        inp_dec_level1 = _cat(self.up2_1(out_dec_level2), out_enc_level1)
+        inp_dec_level1 = _cat(self.up2_1(out_dec_level2, out=first_half(out_enc_level1)), out_enc_level1)
         out_dec_level1 = self.refinement(self.decoder_level1(inp_dec_level1))
         return self.output(out_dec_level1, residual=inp_img)   # `+ inp_img` fused into the conv epilogue
 

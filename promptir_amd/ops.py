@@ -254,21 +254,160 @@ def _bs(t: torch.Tensor) -> int:
 
 
 _WS = {}
+_WS_RETIRED = []   # outgrown buffers stay alive: a captured graph may still hold their addresses
 
 
 def workspace(nfloats: int, device: torch.device, slot: str = "main") -> torch.Tensor:
     """Grow-only scratch buffer per (device, slot).  All kernels of one op are enqueued on the
-    current stream in order, so one buffer per slot is race-free on a single stream."""
-    key = (device.index, slot, _stream())
+    current stream in order, so one buffer per slot is race-free on a single stream.
+    Inside a `deferred_reductions()` scope the partial sums a kernel leaves here are read only at the flush: every
+    request then gets its own piece of a bump-allocated arena instead of the one reused buffer."""
+    st = _stream()
+    if slot == "main" and _DEFER.get(st, 0) > 0:
+        return _arena_take(int(nfloats), device, st)
+    key = (device.index, slot, st)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nfloats:
+        if buf is not None:
+            _WS_RETIRED.append(buf)
         buf = torch.empty(max(int(nfloats), 1 << 16), dtype=torch.float32, device=device)
         _WS[key] = buf
     return buf
 
 
+# ---- deferred, batched second stages of the parameter-gradient reductions (csrc/reduce_batch.hip) ----------------
+DEFER_REDUCE = _os.environ.get("PIR_DEFER_REDUCE", "1") != "0"
+_DEFER = {}     # stream handle -> nesting depth of open deferral scopes
+_ARENAS = {}    # (device index, stream) -> {"bufs": [tensors], "cur": index, "off": floats used in bufs[cur]}
+_DEFER_KEEP = {}   # stream -> tensors that hold queued partial sums (kept alive until the flush)
+
+
+def _arena_take(nfloats: int, device: torch.device, st: int) -> torch.Tensor:
+    a = _ARENAS.setdefault((device.index, st), {"bufs": [], "cur": 0, "off": 0})
+    n = (max(nfloats, 1) + 63) // 64 * 64
+    while True:
+        if a["cur"] < len(a["bufs"]):
+            buf = a["bufs"][a["cur"]]
+            if a["off"] + n <= buf.numel():
+                out = buf[a["off"]:a["off"] + n]
+                a["off"] += n
+                return out
+            a["cur"] += 1
+            a["off"] = 0
+            continue
+        # chunks are never freed or replaced (captured graphs hold their addresses); sized for a block's worth of partials
+        a["bufs"].append(torch.empty(max(n, 1 << 26), dtype=torch.float32, device=device))
+
+
+class deferred_reductions:
+    """Scope in which the reductions behind parameter gradients are queued by the library instead of launched
+    (pir_reduce_defer); `flush_reductions()` then runs them in batched launches.  Only for results nothing on the
+    device reads before the flush."""
+
+    def __init__(self, enabled: bool = True):
+        self.enabled = bool(enabled) and DEFER_REDUCE
+
+    def __enter__(self):
+        if self.enabled:
+            self.st = _stream()
+            depth = _DEFER.get(self.st, 0)
+            if depth == 0:
+                check(_lib.lib.pir_reduce_defer(self.st, 1), "pir_reduce_defer")
+            _DEFER[self.st] = depth + 1
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            depth = _DEFER[self.st] - 1
+            _DEFER[self.st] = depth
+            if depth == 0:
+                check(_lib.lib.pir_reduce_defer(self.st, 0), "pir_reduce_defer")
+        return False
+
+
+class immediate_reductions:
+    """Inside a deferral scope: reductions whose result the NEXT kernel reads (dW_eff, dattn of the MDTA backward)."""
+
+    def __enter__(self):
+        self.st = _stream()
+        self.depth = _DEFER.get(self.st, 0)
+        if self.depth:
+            check(_lib.lib.pir_reduce_defer(self.st, 0), "pir_reduce_defer")
+            _DEFER[self.st] = 0
+        return self
+
+    def __exit__(self, *exc):
+        if self.depth:
+            _DEFER[self.st] = self.depth
+            check(_lib.lib.pir_reduce_defer(self.st, 1), "pir_reduce_defer")
+        return False
+
+
+def keep_until_flush(t: torch.Tensor) -> torch.Tensor:
+    """A tensor of partial sums allocated by the caller (not the arena) whose reduction may be queued."""
+    st = _stream()
+    if _DEFER.get(st, 0) > 0:
+        _DEFER_KEEP.setdefault(st, []).append(t)
+    return t
+
+
+def flush_reductions() -> None:
+    """Run every reduction queued on the current stream (batched launches) and recycle the partial-sum arena."""
+    st = _stream()
+    check(lib.pir_reduce_flush(st), "pir_reduce_flush")
+    _DEFER_KEEP.pop(st, None)
+    for (dev, s), a in _ARENAS.items():
+        if s == st:
+            a["cur"], a["off"] = 0, 0
+
+
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
+
+
+# ---- producers that write straight into a concat buffer (net/model.py:341,347,353,359,365,370: torch.cat along C) ----
+CAT_INPLACE = _os.environ.get("PIR_CAT_INPLACE", "1") != "0"
+
+
+def _alias(buf: torch.Tensor, c0: int, c: int) -> torch.Tensor:
+    """Channels [c0, c0 + c) of the NCHW buffer `buf` as a tensor that SHARES its memory without being an autograd
+    view of it (Tensor.set_): safe to return from an autograd Function's forward as a fresh output."""
+    b, ctot, h, w = buf.shape
+    return torch.empty(0, dtype=buf.dtype, device=buf.device).set_(
+        buf.untyped_storage(), buf.storage_offset() + c0 * h * w, (b, c, h, w), (ctot * h * w, h * w, w, 1))
+
+
+class OutSlot:
+    """Destination of a producer's output: channels [c0, c0 + c) of a pre-allocated concat buffer.  Travels through
+    autograd.Function.apply as a plain Python object (autograd never sees the buffer)."""
+
+    def __init__(self, buf: torch.Tensor, c0: int, c: int):
+        self.buf, self.c0, self.c = buf, c0, c
+
+    def tensor(self, shape) -> Optional[torch.Tensor]:
+        b, _, h, w = self.buf.shape
+        if tuple(shape) != (b, self.c, h, w):
+            raise RuntimeError(f"OutSlot: producer output {tuple(shape)} does not fit slot {(b, self.c, h, w)}")
+        return _alias(self.buf, self.c0, self.c)
+
+
+_CAT_BUFFERS = {}   # storage address -> concat buffer (lets the decoder find the buffer a skip tensor lives in)
+
+
+def new_cat_buffer(like: torch.Tensor, channels: int, h: int, w: int) -> torch.Tensor:
+    """A registered concat buffer.  The registry holds it strongly (the producers' outputs are storage aliases, the
+    tensor object itself would die with the frame that allocated it); entries whose storage nobody else uses any more
+    are dropped here, at the next allocation."""
+    for key in [k for k, t in _CAT_BUFFERS.items() if torch._C._storage_Use_Count(t.untyped_storage()._cdata) <= 2]:
+        del _CAT_BUFFERS[key]          # 2 = the registered tensor + the storage wrapper made for the query
+    buf = torch.empty((like.shape[0], channels, h, w), dtype=torch.float32, device=like.device)
+    _CAT_BUFFERS[buf.untyped_storage().data_ptr()] = buf
+    return buf
+
+
+def cat_buffer_of(t: torch.Tensor) -> Optional[torch.Tensor]:
+    """The registered concat buffer whose memory `t` (or a detached alias of it) lives in, if any."""
+    return _CAT_BUFFERS.get(t.untyped_storage().data_ptr())
 
 
 # ----------------------------------------------------------------------------- raw kernels (no autograd)
@@ -522,11 +661,13 @@ def conv1x1_wgrad(dy: torch.Tensor, x: torch.Tensor, like: torch.Tensor, out: Op
     return dw
 
 
-def conv3x3_forward(x: torch.Tensor, w: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+def conv3x3_forward(x: torch.Tensor, w: torch.Tensor, residual: Optional[torch.Tensor] = None,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
     x = _planes(x)
     b, cin, h, wd = x.shape
     cout = w.shape[0]
-    out = torch.empty((b, cout, h, wd), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((b, cout, h, wd), dtype=torch.float32, device=x.device)
     if residual is not None:
         residual = _planes(residual)
     r_bs = _bs(residual) if residual is not None else 0
@@ -763,7 +904,7 @@ def mdta_attn_backward(dattn, qkv, temperature, heads, attn, gram, sumsq, dqkv, 
         if st != 1000:
             check(st, "pir_mdta_dqk")
             dtemp = _grad_out(temperature, dtemp_out)
-            reduce_partials(dtemp_part, heads, b, dtemp, heads)
+            reduce_partials(keep_until_flush(dtemp_part), heads, b, dtemp, heads)
             return dtemp
     # dq = dG k + alpha_q * q
     gemm_nn(dgram, (heads * c * c, c * c), c, 1, qkv, c_all * hw, (bs, c * hw), hw,
@@ -774,7 +915,7 @@ def mdta_attn_backward(dattn, qkv, temperature, heads, attn, gram, sumsq, dqkv, 
             dqkv, c_all * hw, (qbs, c * hw), hw, c, c, hw, b, heads,
             R=qkv, r_off=c_all * hw, r_batch=(bs, c * hw), ldr=hw, rowscale=alpha_k, rs_batch=(c_all, c))
     dtemp = _grad_out(temperature, dtemp_out)
-    reduce_partials(dtemp_part, heads, b, dtemp, heads)
+    reduce_partials(keep_until_flush(dtemp_part), heads, b, dtemp, heads)
     return dtemp
 
 
@@ -807,8 +948,9 @@ def mdta_core_backward(dout, qkv, temperature, heads, attn, gram, sumsq, dtemp_o
     qbs = c3 * hw
     # dA = dout v^T
     dattn = torch.empty_like(attn)
-    gemm_nt(dout, 0, (dbs, c * hw, 0), hw, qkv, 2 * c_all * hw, (bs, c * hw, 0), hw, dattn, 0, (c * c, c, 1),
-            c, c, hw, b, heads, 1)
+    with immediate_reductions():     # the softmax backward reads dattn next
+        gemm_nt(dout, 0, (dbs, c * hw, 0), hw, qkv, 2 * c_all * hw, (bs, c * hw, 0), hw, dattn, 0, (c * c, c, 1),
+                c, c, hw, b, heads, 1)
     # dv = A^T dout :  A'(m=j, k=i) = attn[i*c + j]
     gemm_nn(attn, (heads * c * c, c * c), 1, c, dout, 0, (dbs, c * hw), hw,
             dqkv, 2 * c_all * hw, (qbs, c * hw), hw, c, c, hw, b, heads)
@@ -854,7 +996,8 @@ def mdta_fold_backward(dx1, qkv, attn, weff, wproj, heads, dqkv, dwproj_out=None
     gemm_nn(weff, (C * C, 0), 1, C, dx1, 0, (dbs, 0), hw, dqkv, 2 * C * hw, (qbs, 0), hw, C, C, hw, b, 1)
     # dW_eff[b] = dx1[b] v[b]^T
     dweff = torch.empty((b, C, C), dtype=torch.float32, device=dev)
-    gemm_nt(dx1, 0, (dbs, 0, 0), hw, qkv, 2 * C * hw, (bs, 0, 0), hw, dweff, 0, (C * C, C, 1), C, C, hw, b, 1, 1)
+    with immediate_reductions():     # dW_proj and dattn below read dW_eff
+        gemm_nt(dx1, 0, (dbs, 0, 0), hw, qkv, 2 * C * hw, (bs, 0, 0), hw, dweff, 0, (C * C, C, 1), C, C, hw, b, 1, 1)
     # dW_proj[:, h-block] = sum_b dW_eff[b][:, h-block] attn[b, h]^T      (contraction over j, then over the batch)
     dwproj = _grad_out(wproj, dwproj_out)
     gemm_nt(dweff, 0, (0, c, C * C), C, attn, 0, (0, c * c, heads * c * c), c, dwproj, 0, (c, C, 1), C, c, c, 1, heads, b)
@@ -876,11 +1019,11 @@ def pixel_unshuffle(x):
     return y
 
 
-def pixel_shuffle(x):
+def pixel_shuffle(x, out=None):
     x = _planes(x)
     b, c4, h, w = x.shape
     c = c4 // 4
-    y = torch.empty((b, c, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    y = out if out is not None else torch.empty((b, c, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
     check(lib.pir_pixel_shuffle2(x.data_ptr(), _bs(x), y.data_ptr(), _bs(y), b, c, h, w, _stream()),
           "pir_pixel_shuffle2")
     return y
@@ -937,19 +1080,20 @@ class Conv1x1Fn(torch.autograd.Function):
 
 class Conv3x3Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, residual):
+    def forward(ctx, x, w, residual, out_slot=None):
         _require_gpu(x, w, residual)
         ctx.save_for_backward(x, w)
         ctx.has_res = residual is not None
         ctx.sink = _sink(w)
-        return conv3x3_forward(x, w, residual)
+        out = out_slot.tensor((x.shape[0], w.shape[0], x.shape[2], x.shape[3])) if out_slot is not None else None
+        return conv3x3_forward(x, w, residual, out)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dx = conv3x3_dgrad(dy, w) if ctx.needs_input_grad[0] else None
         dw = conv3x3_wgrad(dy, x, w, ctx.sink) if ctx.needs_input_grad[1] else None
-        return dx, _ret(dw, ctx.sink), (dy if ctx.has_res and ctx.needs_input_grad[2] else None)
+        return dx, _ret(dw, ctx.sink), (dy if ctx.has_res and ctx.needs_input_grad[2] else None), None
 
 
 class DwConvFn(torch.autograd.Function):
@@ -1155,7 +1299,8 @@ class TransformerBlockFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, temperature, wqkv, wdw1, wproj, n2w, n2b, win, wdw2, wout, heads, no_grad=False):
+    def forward(ctx, x, n1w, n1b, temperature, wqkv, wdw1, wproj, n2w, n2b, win, wdw2, wout, heads, no_grad=False,
+                out_slot=None):
         _require_gpu(x, n1w, n1b, temperature, wqkv, wdw1, wproj, n2w, n2b, win, wdw2, wout)
         # no_grad forward (inference, tiled restoration): nothing is saved, so the LayerNorms can be applied as the
         # consuming 1x1 convolution loads its activations (pir_ln_conv1x1_fwd) wherever that kernel serves the shape
@@ -1197,7 +1342,8 @@ class TransformerBlockFn(torch.autograd.Function):
             xn2, m2, r2 = layernorm_forward(x1, n2w, n2b)
             h0 = conv1x1_forward(xn2, win)
         g = dwconv_gate_forward(h0, wdw2)
-        x2 = conv1x1_forward(g, wout, residual=x1)
+        # `out_slot`: the block's output goes straight into its half of the concat buffer it is headed for
+        x2 = conv1x1_forward(g, wout, residual=x1, out=out_slot.tensor(x.shape) if out_slot is not None else None)
         if infer:
             return x2
         ctx.heads = heads
@@ -1216,6 +1362,24 @@ class TransformerBlockFn(torch.autograd.Function):
         # The four 1x1 weight gradients feed nothing downstream in this backward: they run on a side stream
         # beside the input-gradient chain (joined before returning).
         side = _SideWgrads(dx2.device)
+        # Every reduction behind a parameter gradient of this block (four split-K weight gradients, dW_proj, two
+        # depthwise weight gradients, two LayerNorm dweight / dbias pairs, dtemperature) is queued and runs as ONE
+        # batched launch at the end of the block instead of ~11 launches of ~5 us spread over the chain.  (Not beside
+        # side streams: the queue is per stream.)
+        defer = deferred_reductions(side.side is None)
+        defer.__enter__()
+        try:
+            return TransformerBlockFn._backward_body(ctx, dx2, side)
+        finally:
+            defer.__exit__(None, None, None)
+            if defer.enabled:
+                flush_reductions()
+
+    @staticmethod
+    def _backward_body(ctx, dx2, side):
+        (x, n1w, temperature, wqkv, wdw1, wproj, n2w, win, wdw2, wout,
+         xn1, m1, r1, qkv0, qkv, attn, gram, sumsq, out, x1, xn2, m2, r2, h0, g, n1b, n2b) = ctx.saved_tensors
+        s_n1w, s_n1b, s_t, s_qkv, s_dw1, s_proj, s_n2w, s_n2b, s_in, s_dw2, s_out = ctx.sinks
         # ---- GDFN branch
         dg = conv1x1_dgrad(dx2, wout)
         d_wout = side.wgrad(dx2, g, wout, s_out)
@@ -1253,7 +1417,7 @@ class TransformerBlockFn(torch.autograd.Function):
         return (dx, _ret(d_n1w, s_n1w), _ret(d_n1b, s_n1b) if ctx.with_bias[0] else None, _ret(d_temp, s_t),
                 _ret(d_wqkv, s_qkv), _ret(d_wdw1, s_dw1), _ret(d_wproj, s_proj),
                 _ret(d_n2w, s_n2w), _ret(d_n2b, s_n2b) if ctx.with_bias[1] else None,
-                _ret(d_win, s_in), _ret(d_wdw2, s_dw2), _ret(d_wout, s_out), None, None)
+                _ret(d_win, s_in), _ret(d_wdw2, s_dw2), _ret(d_wout, s_out), None, None, None)
 
 
 class PixelUnshuffleFn(torch.autograd.Function):
@@ -1269,13 +1433,14 @@ class PixelUnshuffleFn(torch.autograd.Function):
 
 class PixelShuffleFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, out_slot=None):
         _require_gpu(x)
-        return pixel_shuffle(x)
+        out = out_slot.tensor((x.shape[0], x.shape[1] // 4, 2 * x.shape[2], 2 * x.shape[3])) if out_slot is not None else None
+        return pixel_shuffle(x, out)
 
     @staticmethod
     def backward(ctx, dy):
-        return pixel_unshuffle(dy)
+        return pixel_unshuffle(dy), None
 
 
 class CatChannelsFn(torch.autograd.Function):
@@ -1285,11 +1450,25 @@ class CatChannelsFn(torch.autograd.Function):
     def forward(ctx, a, b):
         _require_gpu(a, b)
         ctx.ca = a.shape[1]
+        buf = cat_buffer_of(a)
+        if buf is not None and CatChannelsFn.adjacent(a, b, buf):
+            # both producers already wrote their halves into the registered concat buffer: the concat is the buffer
+            return _alias(buf, 0, buf.shape[1])
         out = torch.empty((a.shape[0], a.shape[1] + b.shape[1], a.shape[2], a.shape[3]), dtype=torch.float32,
                           device=a.device)
         copy_planes(a, out[:, :ctx.ca])
         copy_planes(b, out[:, ctx.ca:])
         return out
+
+    @staticmethod
+    def adjacent(a, b, buf) -> bool:
+        bb, ctot, h, w = buf.shape
+        hw = h * w
+        same = a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() == buf.untyped_storage().data_ptr()
+        full = (bb, a.shape[1] + b.shape[1], a.shape[2], a.shape[3]) == tuple(buf.shape)
+        strides = tuple(a.stride()) == tuple(b.stride()) == (ctot * hw, hw, w, 1) or bb == 1 and a.is_contiguous() and b.is_contiguous()
+        return bool(same and full and strides and a.storage_offset() == buf.storage_offset()
+                    and b.storage_offset() == buf.storage_offset() + a.shape[1] * hw)
 
     @staticmethod
     def backward(ctx, dy):

@@ -757,3 +757,58 @@ def test_side_streams_refused_inside_a_multi_stream_capture(monkeypatch):
         for s in (s1, s2):
             with torch.cuda.stream(s):
                 ops._SideWgrads(dev)                  # side streams off: nothing to refuse
+
+
+@pytest.mark.parametrize("dim,heads,hw", [(48, 1, (64, 64)), (96, 2, (16, 24)), (192, 4, (8, 8))])
+def test_deferred_batched_reductions_are_bit_identical(dim, heads, hw, monkeypatch):
+    """reduce_batch.hip: the ~11 second-stage reductions behind a block's parameter gradients queued and run as one
+    batched launch at the end of the block backward give bit-identical gradients to the immediate launches (same device
+    functions, same grouping of the splits), and nothing stays queued."""
+    import promptir_amd.model as M
+    from promptir_amd import _lib, ops
+
+    torch.manual_seed(3)
+    blk = M.TransformerBlock(dim, heads, 2.66, False, "WithBias").to(DEV)
+    x0 = rnd("x", 2, dim, *hw).to(DEV)
+    dy = rnd("dy", 2, dim, *hw).to(DEV)
+    grads = {}
+    for mode in (False, True):
+        monkeypatch.setattr(ops, "DEFER_REDUCE", mode)
+        for p in blk.parameters():
+            p.grad = None
+        with ops.side_streams(False):
+            x = x0.clone().requires_grad_(True)
+            blk(x).backward(dy)
+        torch.cuda.synchronize()
+        assert _lib.lib.pir_reduce_pending(torch.cuda.current_stream().cuda_stream) == 0
+        grads[mode] = {n: p.grad.clone() for n, p in blk.named_parameters()}
+        grads[mode]["x"] = x.grad.clone()
+    for n, g in grads[False].items():
+        assert torch.equal(g, grads[True][n]), n
+
+
+def test_reduce_queue_flushes_before_two_writers_of_one_destination():
+    """Two queued reductions into the same output would race inside one batched launch: the second submit flushes
+    the queue first; accumulate semantics survive the deferral."""
+    from promptir_amd import _lib, ops
+
+    st = torch.cuda.current_stream().cuda_stream
+    parts = rnd("p", 70, 200).to(DEV)
+    out = torch.zeros(200, device=DEV)
+    with ops.deferred_reductions():
+        ops.reduce_partials(parts, 200, 70, out, 200)
+        assert _lib.lib.pir_reduce_pending(st) == 1
+        ops.reduce_partials(parts, 200, 70, out, 200, alpha=0.5, accumulate=True)      # same destination: flushes the first
+        assert _lib.lib.pir_reduce_pending(st) == 1
+        other = torch.zeros(200, device=DEV)
+        ops.reduce_partials(parts, 200, 33, other, 200)                                # GR = 4 kind beside a GR = 16 kind
+        assert _lib.lib.pir_reduce_pending(st) == 2
+    ops.flush_reductions()
+    assert _lib.lib.pir_reduce_pending(st) == 0
+    ref = parts.cpu().double().sum(0)
+    assert float((out.cpu().double() - 1.5 * ref).abs().max()) <= 3e-6 * float(ref.abs().max())
+    ref33 = parts[:33].cpu().double().sum(0)
+    assert float((other.cpu().double() - ref33).abs().max()) <= 3e-6 * float(ref33.abs().max())
+    plain = torch.zeros(200, device=DEV)
+    ops.reduce_partials(parts, 200, 33, plain, 200)                                    # immediate form: same bits
+    assert torch.equal(plain, other)

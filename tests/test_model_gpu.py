@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from oracle import promptir_ref as O
+from promptir_amd import weights as W
 from tests import util
 
 pytestmark = pytest.mark.gpu
@@ -219,3 +220,49 @@ def test_training_step_without_the_normalised_tensors_equals_the_step_that_mater
         gb = results[False][1][k]
         scale = max(float(gb.abs().max()), 1e-12)
         assert float((ga - gb).abs().max()) <= 1e-3 * scale, k     # two summation orders; accuracy is the golden tests' matter
+
+
+def test_concat_producers_write_in_place():
+    """net/model.py:341-370: the six torch.cat.  With the producers writing their halves straight into pre-allocated
+    concat buffers the step launches NO plane copies for them, and output, loss and every gradient are bit-identical to
+    the copying form (same kernels, same operands, other destination addresses)."""
+    from promptir_amd import ops
+
+    dev = torch.device("cuda:0")
+    ctor = dict(decoder=True, num_blocks=[1, 2, 1, 2], num_refinement_blocks=1)
+    deg, clean = W.synthetic_pair(2, 64, 64, sigma=[25, 50], seed=31)
+    x, t = torch.from_numpy(deg).to(dev), torch.from_numpy(clean).to(dev)
+    res = {}
+    for inplace in (False, True):
+        ops.CAT_INPLACE = inplace
+        try:
+            net, _ = _net(ctor, 17, dev)
+            copies = [0]
+            real = ops.copy_planes
+
+            def counting(*a, **k):
+                copies[0] += 1
+                return real(*a, **k)
+
+            ops.copy_planes = counting
+            try:
+                y = net(x)
+                fwd_copies = copies[0]
+                loss = ops.l1_loss(y, t)
+                loss.backward()
+            finally:
+                ops.copy_planes = real
+            torch.cuda.synchronize()
+            res[inplace] = (y.detach().clone(), float(loss), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None},
+                            fwd_copies)
+        finally:
+            ops.CAT_INPLACE = True
+    assert res[False][3] == 12 and res[True][3] == 0          # two plane copies per concat before, none now
+    assert torch.equal(res[False][0], res[True][0]) and res[False][1] == res[True][1]
+    assert res[False][2].keys() == res[True][2].keys()
+    for n, g in res[False][2].items():
+        assert torch.equal(g, res[True][2][n]), n
+    # no_grad forward (inference / tiled restoration) takes the same route
+    net, _ = _net(ctor, 17, dev)
+    with torch.no_grad():
+        assert torch.equal(net(x), res[True][0])
