@@ -334,7 +334,7 @@ def main():
             # their backward products dW_eff, dv, dq, dk - the calls ops.py files under the "mdta" tag
             "mdta_contractions": family(lambda n, tag: tag == "mdta" and n in ("pir_gemm_nn", "pir_gemm_nt", "pir_mdta_dqk"), "mfma"),
             # every weight gradient over the pixels that is not an MDTA product
-            "weight_gradients": family(lambda n, tag: tag != "mdta" and n in ("pir_gemm_nt", "pir_conv1x1_wgrad_ln", "pir_conv3x3_wgrad"), "mfma"),
+            "weight_gradients": family(lambda n, tag: tag != "mdta" and n in ("pir_gemm_nt", "pir_gemm_nt_group", "pir_conv1x1_wgrad_ln", "pir_conv3x3_wgrad"), "mfma"),
             "dense_conv3x3": family(lambda n, tag: n in ("pir_conv3x3", "pir_conv3x3_x3"), "mfma"),
         }
         # HBM bytes from the committed PMC profile of this build (rocprofv3 cannot run inside the timed process):

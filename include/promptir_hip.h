@@ -155,6 +155,11 @@ typedef struct {
 } pir_gemm_nt_t;
 size_t pir_gemm_nt_ws_floats(int M1, int M2, int N, int O, int BR);
 int pir_gemm_nt(const pir_gemm_nt_t* args, pir_stream_t stream);
+/* n <= 4 products in ONE launch: the 1x1 weight gradients of one TransformerBlock (net/model.py:88,92,111,113) at the
+ * 32^2 / 16^2 levels, where each alone has too few output tiles for the chip and splits its pixel axis 40 - 160 ways.
+ * Every problem is a pir_gemm_nt_t of its own (O1 = O2 = 1, own ws); problems the grouped kernel does not serve run one
+ * by one through pir_gemm_nt.  Same results as pir_gemm_nt up to the order of the split-K sum (deterministic). */
+int pir_gemm_nt_group(const pir_gemm_nt_t* probs, int n, pir_stream_t stream);
 
 /* bf16x3 matrix-core form of pir_conv3x3: A3 = pir_split_bf16x3_taps() of the weights, layout
  * [3 parts][9 taps][a3_kp/16][M][16] bf16 with W(tap, m, k) = W[(flip ? 8-tap : tap)*st + m*sm + k*sk].

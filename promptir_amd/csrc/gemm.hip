@@ -502,14 +502,14 @@ constexpr int X3_BK = 16;
 // QUAD (plain operands only): four lanes read one row's 64 bytes of a stage (16 bytes each) and each lane splits and
 // stores its 4 pixels (8 bytes per piece), instead of two lanes x two 16-byte loads per row: one L1 request per row and
 // stage instead of two.
-template <int TM, int TN, int WM, int WN, bool TAPS = false, bool QUAD = false>
-__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WM * WN >= 8 ? 4 : 3)))
-void gemm_nt_x3_kernel(NTParams p) {
+// (lin, ntiles, nsplits, nbatch): the workgroup's linear index inside ITS problem and that problem's grid extents - the
+// stand-alone kernel passes its own grid, the grouped kernel (several problems in one launch) the problem's slice of it
+template <int TM, int TN, int WM, int WN, bool TAPS, bool QUAD>
+__device__ __forceinline__ void gemm_nt_x3_body(const NTParams& p, pir_bf16x8* smem, int lin, int ntiles, int nsplits, int nbatch) {
   static_assert(!(TAPS && QUAD), "the tap-shifted operand keeps the fragment mapping");
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, T = WM * WN * 64;
   constexpr int XKS = BM + 4, YKS = BN + 4;            // 16-byte units between the two k-groups
   constexpr int XU = 2 * XKS, YU = 2 * YKS, PART = XU + YU, STAGE = 3 * PART;
-  __shared__ pir_bf16x8 smem[2 * STAGE];
 
   const pir_gemm_nt_t& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -517,12 +517,11 @@ void gemm_nt_x3_kernel(NTParams p) {
   const int tiles_i = (g.M1 + BM - 1) / BM;
   // XCD-aware order: the output tiles of one split (same pixel range => same operand rows) are neighbours in the
   // logical order, so they run on one XCD and share its L2 instead of each XCD fetching the rows from HBM
-  const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-  const int rr = pir_xcd_remap(lin, gridDim.x * gridDim.y * gridDim.z);
-  const int tile = rr % (int)gridDim.x, rest = rr / (int)gridDim.x;
+  const int rr = pir_xcd_remap(lin, ntiles * nsplits * nbatch);
+  const int tile = rr % ntiles, rest = rr / ntiles;
   const int i0 = (tile % tiles_i) * BM, j0 = (tile / tiles_i) * BN;
-  const int split = rest % (int)gridDim.y;
-  const int o = rest / (int)gridDim.y, o1 = o / g.O2, o2 = o % g.O2;
+  const int split = rest % nsplits;
+  const int o = rest / nsplits, o1 = o / g.O2, o2 = o % g.O2;
   const float* __restrict__ Xb = g.X + o1 * g.x_s1 + o2 * g.x_s2;
   const float* __restrict__ Yb = g.Y + o1 * g.y_s1 + o2 * g.y_s2;
 
@@ -782,6 +781,37 @@ void gemm_nt_x3_kernel(NTParams p) {
     }
 }
 
+template <int TM, int TN, int WM, int WN, bool TAPS = false, bool QUAD = false>
+__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WM * WN >= 8 ? 4 : 3)))
+void gemm_nt_x3_kernel(NTParams p) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  __shared__ pir_bf16x8 smem[2 * 3 * (2 * (BM + 4) + 2 * (BN + 4))];
+  const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  gemm_nt_x3_body<TM, TN, WM, WN, TAPS, QUAD>(p, smem, lin, (int)gridDim.x, (int)gridDim.y, (int)gridDim.z);
+}
+
+// Several weight gradients of ONE transformer block in one launch (the low-resolution levels: four launches of 16 - 64
+// output tiles each had to split the pixel axis 40 - 160 ways to fill the chip and wrote as many partial tiles; together
+// they need a quarter of the splits).  The problems share the tile shape; each keeps its own workspace and reduction.
+constexpr int NT_GROUP_MAX = 4;
+struct NTGroup {
+  NTParams p[NT_GROUP_MAX];
+  int first[NT_GROUP_MAX + 1];   // first workgroup of every problem
+  int ntiles[NT_GROUP_MAX];
+  int n;
+};
+
+template <int TM, int TN, int WM, int WN, bool QUAD>
+__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(3)))
+void gemm_nt_x3_group_kernel(NTGroup grp) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  __shared__ pir_bf16x8 smem[2 * 3 * (2 * (BM + 4) + 2 * (BN + 4))];
+  int k = 0;
+  while (k + 1 < grp.n && (int)blockIdx.x >= grp.first[k + 1]) ++k;
+  k = __builtin_amdgcn_readfirstlane(k);
+  gemm_nt_x3_body<TM, TN, WM, WN, false, QUAD>(grp.p[k], smem, (int)blockIdx.x - grp.first[k], grp.ntiles[k], grp.p[k].splits, 1);
+}
+
 // second stage of every split-K product: reduce_batch.hip (launched at once, or queued inside a deferral scope)
 }  // namespace
 int pir_nt_reduce_submit(const float* ws, int splits, long O, int M1, int M2, float* G, long g_so, long g_si, long g_sj, long g_st,
@@ -1027,6 +1057,92 @@ extern "C" int pir_gemm_nt(const pir_gemm_nt_t* a, pir_stream_t stream) {
     int m = g.M1; g.M1 = g.M2; g.M2 = m;
   }
   return launch_nt(p, a->ws_floats, 0, 0L, (hipStream_t)stream);
+}
+
+// Up to four split-K products in ONE launch (the 1x1 weight gradients of a transformer block at the 32^2 / 16^2 levels,
+// net/model.py:88,92,111,113): same tile shape for all, one split count for the whole launch chosen for the SUM of the
+// tiles, every problem with its own workspace and its own (deferrable) second stage.  Problems the grouped kernel does
+// not serve (unaligned rows, different tile shapes, the "X private" shapes) are launched one by one: the results are
+// those of pir_gemm_nt either way, up to the order of the split-K sum.
+extern "C" int pir_gemm_nt_group(const pir_gemm_nt_t* probs, int n, pir_stream_t stream) {
+  PIR_CHECK_ARG(probs && n > 0 && n <= NT_GROUP_MAX);
+  hipStream_t s = (hipStream_t)stream;
+  auto al = [](const float* q, long s1, long s2, long sr, long ld) {
+    return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && s1 % 4 == 0 && s2 % 4 == 0 && sr % 4 == 0 && ld % 4 == 0;
+  };
+  NTGroup grp;
+  grp.n = 0;
+  int cfg = -1, quad = -1;
+  long tiles_total = 0, total_chunks = -1;
+  bool ok = n > 1 && g_nt_cfg < 0 && g_nt_splits == 0 && g_nt_x3 != 0;
+  for (int k = 0; k < n && ok; ++k) {
+    const pir_gemm_nt_t* a = &probs[k];
+    PIR_CHECK_ARG(a->X && a->Y && a->G && a->ws && a->M1 > 0 && a->M2 > 0 && a->N > 0 && a->BR > 0);
+    NTParams& p = grp.p[k];
+    p.g = *a;
+    pir_gemm_nt_t& g = p.g;
+    if (g.O1 * g.O2 != 1 || g.H != 0) { ok = false; break; }
+    if (g.M2 > g.M1) {   // larger extent on the tile rows (as pir_gemm_nt)
+      const float* t = g.X; g.X = g.Y; g.Y = t;
+      long v;
+      v = g.x_sr; g.x_sr = g.y_sr; g.y_sr = v;
+      v = g.ldx; g.ldx = g.ldy; g.ldy = v;
+      v = g.g_si; g.g_si = g.g_sj; g.g_sj = v;
+      int m = g.M1; g.M1 = g.M2; g.M2 = m;
+    }
+    if (!(g.N % 4 == 0 && al(g.X, 0, 0, g.x_sr, g.ldx) && al(g.Y, 0, 0, g.y_sr, g.ldy))) { ok = false; break; }
+    int xs = 0;
+    { pir_gemm_nt_t probe = g; if (pir_nt_xp_splits(&probe) > 0) { ok = false; break; } (void)xs; }
+    const NTPlan pl = nt_plan(g.M1, g.M2, g.N, 1, g.BR, X3_BK, true, false);
+    const int q = (g.N >= 1024 && pl.cfg != 1) ? 1 : 0;
+    if (pl.cfg != 2 && pl.cfg != 3) { ok = false; break; }
+    if (cfg < 0) { cfg = pl.cfg; quad = q; }
+    if (pl.cfg != cfg || q != quad) { ok = false; break; }
+    const long chunks = (long)g.BR * pl.chunks_per_r;
+    if (total_chunks < 0) total_chunks = chunks;
+    if (chunks != total_chunks || chunks >= 2147483647L) { ok = false; break; }
+    p.chunks_per_r = pl.chunks_per_r;
+    p.tap_sign = 0;
+    p.magic_w = pir_magic(1u);
+    grp.ntiles[k] = (int)(pir_cdiv(g.M1, pl.bm) * pir_cdiv(g.M2, pl.bn));
+    tiles_total += grp.ntiles[k];
+    grp.n = k + 1;
+  }
+  if (!ok) {
+    for (int k = 0; k < n; ++k) {
+      const int st = pir_gemm_nt(&probs[k], stream);
+      if (st) return st;
+    }
+    return PIR_OK;
+  }
+  // one split count for the launch: all workgroups resident at once (as nt_plan), at least 128 pixels per split
+  long want = (long)g_nt_want_half * PIR_NUM_CU / (2 * tiles_total);
+  if (want < 1) want = 1;
+  const long max_by_work = total_chunks / (128 / X3_BK) > 0 ? total_chunks / (128 / X3_BK) : 1;
+  long sp = want < max_by_work ? want : max_by_work;
+  if (sp > 1024) sp = 1024;
+  long blocks = 0;
+  for (int k = 0; k < grp.n; ++k) {
+    NTParams& p = grp.p[k];
+    if ((size_t)sp * p.g.M1 * p.g.M2 > p.g.ws_floats) return PIR_ENOMEM;
+    p.splits = (int)sp;
+    grp.first[k] = (int)blocks;
+    blocks += (long)grp.ntiles[k] * sp;
+  }
+  for (int k = grp.n; k <= NT_GROUP_MAX; ++k) grp.first[k] = (int)blocks;
+  const dim3 grid((unsigned)blocks), block(256);
+  if (cfg == 2 && quad) hipLaunchKernelGGL((gemm_nt_x3_group_kernel<1, 3, 4, 1, true>), grid, block, 0, s, grp);
+  else if (cfg == 2) hipLaunchKernelGGL((gemm_nt_x3_group_kernel<1, 3, 4, 1, false>), grid, block, 0, s, grp);
+  else if (quad) hipLaunchKernelGGL((gemm_nt_x3_group_kernel<2, 2, 2, 2, true>), grid, block, 0, s, grp);
+  else hipLaunchKernelGGL((gemm_nt_x3_group_kernel<2, 2, 2, 2, false>), grid, block, 0, s, grp);
+  int st = pir_launch_status();
+  if (st) return st;
+  for (int k = 0; k < grp.n; ++k) {
+    const pir_gemm_nt_t& g = grp.p[k].g;
+    st = pir_nt_reduce_submit(g.ws, (int)sp, 1, g.M1, g.M2, g.G, g.g_so, g.g_si, g.g_sj, 0L, g.alpha, g.accumulate, s);
+    if (st) return st;
+  }
+  return PIR_OK;
 }
 
 // Dense 3x3 weight gradient in one launch: dW[co][ci][tap] = sum_{b,p} dy[b][co][p] * x[b][ci][p + s(tap)].

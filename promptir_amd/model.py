@@ -361,14 +361,17 @@ class PromptIR(nn.Module):
         b, _, h, w = inp_img.shape
         dim = self.patch_embed.proj.out_channels
         place = ops.CAT_INPLACE and self.decoder_level1[0].attn.qkv.bias is None
-        c6 = ops.new_cat_buffer(inp_img, 2 * dim, h, w) if place else None                # [up2_1 | enc1]
-        c4 = ops.new_cat_buffer(inp_img, 4 * dim, h // 2, w // 2) if place else None      # [up3_2 | enc2]
-        c2 = ops.new_cat_buffer(inp_img, 6 * dim, h // 4, w // 4) if place else None      # [up4_3 | enc3]
         # every encoder output feeds the next level AND the decoder's skip connection: ops.fork sums the two
-        # gradients with the library's own kernel
+        # gradients with the library's own kernel.  (Each buffer is allocated right before its first producer runs: the
+        # registry drops buffers nobody has written into yet at the next allocation.)
+        c6 = ops.new_cat_buffer(inp_img, 2 * dim, h, w) if place else None                # [up2_1 | enc1]
         out_enc_level1, skip1 = ops.fork(_run_stage(self.encoder_level1, inp_enc_level1, _slot(c6, dim, dim)))
-        out_enc_level2, skip2 = ops.fork(_run_stage(self.encoder_level2, self.down1_2(out_enc_level1), _slot(c4, 2 * dim, 2 * dim)))
-        out_enc_level3, skip3 = ops.fork(_run_stage(self.encoder_level3, self.down2_3(out_enc_level2), _slot(c2, 2 * dim, 4 * dim)))
+        x2 = self.down1_2(out_enc_level1)
+        c4 = ops.new_cat_buffer(inp_img, 4 * dim, h // 2, w // 2) if place else None      # [up3_2 | enc2]
+        out_enc_level2, skip2 = ops.fork(_run_stage(self.encoder_level2, x2, _slot(c4, 2 * dim, 2 * dim)))
+        x3 = self.down2_3(out_enc_level2)
+        c2 = ops.new_cat_buffer(inp_img, 6 * dim, h // 4, w // 4) if place else None      # [up4_3 | enc3]
+        out_enc_level3, skip3 = ops.fork(_run_stage(self.encoder_level3, x3, _slot(c2, 2 * dim, 4 * dim)))
         return skip1, skip2, skip3, self.down3_4(out_enc_level3)
 
     def run_latent(self, inp_latent):

@@ -50,6 +50,8 @@ class _TimedLib:
         if name == "pir_gemm_nt":
             g = args[0]._obj
             return 4.0 * g.O1 * g.O2 * g.BR * (g.M1 + g.M2) * g.N
+        if name == "pir_gemm_nt_group":
+            return sum(4.0 * g.BR * (g.M1 + g.M2) * g.N for g in list(args[0])[:args[1]])
         if name == "pir_conv1x1_dgrad_ln_bwd":     # dy read, x and the residual gradient read, dx written, statistics read
             k, (b, c, hw) = args[4], args[18:21]
             return 4.0 * b * hw * (k + 3 * c + 2)
@@ -95,6 +97,8 @@ class _TimedLib:
         if name == "pir_gemm_nt":
             g = args[0]._obj
             return 2.0 * g.M1 * g.M2 * g.N * g.O1 * g.O2 * g.BR
+        if name == "pir_gemm_nt_group":
+            return sum(2.0 * g.M1 * g.M2 * g.N * g.BR for g in list(args[0])[:args[1]])
         if name == "pir_conv1x1_dgrad_ln_bwd":
             k, (b, c, hw) = args[4], args[18:21]
             return 2.0 * c * k * hw * b
@@ -449,6 +453,31 @@ def gemm_nt(X: torch.Tensor, x_off: int, x_str: Tuple[int, int, int], ldx: int,
     g.ws, g.ws_floats = ws.data_ptr(), ws.numel()
     g.alpha, g.accumulate = alpha, int(accumulate)
     check(lib.pir_gemm_nt(C.byref(g), _stream()), "pir_gemm_nt")
+
+
+NT_GROUP = _os.environ.get("PIR_NT_GROUP", "1") != "0"     # low-resolution weight gradients of a block in one launch
+NT_GROUP_MAX_HW = int(_os.environ.get("PIR_NT_GROUP_MAX_HW", "1024"))
+
+
+def conv1x1_wgrad_group(items) -> None:
+    """[(dy, x, dw)]: dW_k = sum_b dy_k[b] x_k[b]^T for up to four 1x1 convolutions in ONE launch (pir_gemm_nt_group):
+    the weight gradients of a block at the 32^2 / 16^2 levels, each of which alone has too few output tiles for the chip."""
+    probs = (_lib.GemmNT * len(items))()
+    keep = []
+    for k, (dy, x, dw) in enumerate(items):
+        dy, x = _planes(dy), _planes(x)
+        b, cout, h, wd = dy.shape
+        cin, hw = x.shape[1], h * wd
+        ws = workspace(lib.pir_gemm_nt_ws_floats(cout, cin, hw, 1, b), x.device)
+        g = probs[k]
+        g.X, g.x_s1, g.x_s2, g.x_sr, g.ldx = dy.data_ptr(), 0, 0, _bs(dy), hw
+        g.Y, g.y_s1, g.y_s2, g.y_sr, g.ldy = x.data_ptr(), 0, 0, _bs(x), hw
+        g.G, g.g_so, g.g_si, g.g_sj = dw.data_ptr(), 0, cin, 1
+        g.M1, g.M2, g.N, g.O1, g.O2, g.BR = cout, cin, hw, 1, 1, b
+        g.ws, g.ws_floats = ws.data_ptr(), ws.numel()
+        g.alpha, g.accumulate = 1.0, 0
+        keep += [dy, x, ws]
+    check(lib.pir_gemm_nt_group(probs, len(items), _stream()), "pir_gemm_nt_group")
 
 
 # ---- bf16x3 weight pieces (pir_split_bf16x3), cached per weight tensor OBJECT and orientation.
@@ -1265,6 +1294,7 @@ class _SideWgrads:
             if self.side is None:
                 self.side = _SIDE_STREAMS[key] = torch.cuda.Stream(device)
         self.used = False
+        self.pending = []
 
     def wgrad(self, dy, x, like, sink, ln=None):
         """`ln` = (mean, rstd, weight, bias): x is the INPUT of the LayerNorm in front of the convolution (the normalised
@@ -1272,6 +1302,12 @@ class _SideWgrads:
         dw = _grad_out(like, sink)
         run = (lambda: conv1x1_wgrad(dy, x, like, dw)) if ln is None else (lambda: conv1x1_wgrad_ln(dy, x, *ln, like, dw))
         if self.side is None:
+            # low-resolution levels: the block's weight gradients wait for `join()` and go out as ONE grouped launch
+            # (inside a deferral scope only: each problem then keeps a workspace piece of its own until the flush)
+            if (ln is None and NT_GROUP and USE_X3 and dy.shape[2] * dy.shape[3] <= NT_GROUP_MAX_HW
+                    and _DEFER.get(_stream(), 0) > 0):
+                self.pending.append((dy, x, dw))
+                return dw
             return run()
         ev = torch.cuda.Event()
         ev.record(self.main)
@@ -1284,6 +1320,12 @@ class _SideWgrads:
         return dw
 
     def join(self):
+        while self.pending:
+            chunk, self.pending = self.pending[:4], self.pending[4:]
+            if len(chunk) == 1:
+                conv1x1_wgrad(chunk[0][0], chunk[0][1], chunk[0][2], chunk[0][2])
+            else:
+                conv1x1_wgrad_group(chunk)
         if self.used:
             ev = torch.cuda.Event()
             ev.record(self.side)

@@ -812,3 +812,30 @@ def test_reduce_queue_flushes_before_two_writers_of_one_destination():
     plain = torch.zeros(200, device=DEV)
     ops.reduce_partials(parts, 200, 33, plain, 200)                                    # immediate form: same bits
     assert torch.equal(plain, other)
+
+
+@pytest.mark.parametrize("c,hw,b", [(192, (32, 32), 4), (384, (16, 16), 3), (192, (8, 24), 2)])
+def test_grouped_weight_gradients_of_a_low_resolution_block(c, hw, b):
+    """pir_gemm_nt_group: the four 1x1 weight gradients of a block at the 32^2 / 16^2 levels (net/model.py:88,92,111,113)
+    as ONE launch against autograd on the CPU and against the four separate launches (same tile kernels; the split
+    count differs, so agreement is to rounding, not bitwise); run twice: deterministic."""
+    from promptir_amd import ops
+
+    hid = int(c * 2.66)
+    shapes = [(3 * c, c), (c, c), (2 * hid, c), (c, hid)]            # qkv, project_out (attention), project_in, project_out
+    items, refs = [], []
+    for k, (cout, cin) in enumerate(shapes):
+        dy, x = rnd(f"dy{k}", b, cout, *hw), rnd(f"x{k}", b, cin, *hw)
+        refs.append(torch.einsum("bohw,bihw->oi", dy.double(), x.double()).float().view(cout, cin, 1, 1))
+        items.append((dy.to(DEV), x.to(DEV), torch.empty(cout, cin, 1, 1, device=DEV)))
+    outs = []
+    for rep in range(2):
+        with ops.deferred_reductions():
+            ops.conv1x1_wgrad_group(items)
+        ops.flush_reductions()
+        outs.append([dw.clone() for _, _, dw in items])
+    for k, ref in enumerate(refs):
+        close(outs[0][k], ref, rtol=5e-5)
+        assert torch.equal(outs[0][k], outs[1][k])
+        single = ops.conv1x1_wgrad(items[k][0], items[k][1], items[k][2].new_empty(items[k][2].shape))
+        close(outs[0][k], single.cpu(), rtol=2e-6)
