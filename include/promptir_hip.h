@@ -160,6 +160,10 @@ int pir_gemm_nt(const pir_gemm_nt_t* args, pir_stream_t stream);
  * Every problem is a pir_gemm_nt_t of its own (O1 = O2 = 1, own ws); problems the grouped kernel does not serve run one
  * by one through pir_gemm_nt.  Same results as pir_gemm_nt up to the order of the split-K sum (deterministic). */
 int pir_gemm_nt_group(const pir_gemm_nt_t* probs, int n, pir_stream_t stream);
+/* Host-only: workspace floats a call really needs (its actual split count; pir_gemm_nt_ws_floats is the worst case over
+ * every plan and far larger) - for callers that give every call a workspace piece of its own (deferred reductions). */
+size_t pir_gemm_nt_ws_needed(const pir_gemm_nt_t* args);
+size_t pir_gemm_nt_group_ws_needed(const pir_gemm_nt_t* probs, int n, int k);
 
 /* bf16x3 matrix-core form of pir_conv3x3: A3 = pir_split_bf16x3_taps() of the weights, layout
  * [3 parts][9 taps][a3_kp/16][M][16] bf16 with W(tap, m, k) = W[(flip ? 8-tap : tap)*st + m*sm + k*sk].

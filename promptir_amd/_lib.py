@@ -66,6 +66,8 @@ SIGNATURES = {
     "pir_gemm_nt_ws_floats": (Z, [I, I, I, I, I]),
     "pir_gemm_nt": (I, [C.POINTER(GemmNT), S]),
     "pir_gemm_nt_group": (I, [C.POINTER(GemmNT), I, S]),
+    "pir_gemm_nt_ws_needed": (Z, [C.POINTER(GemmNT)]),
+    "pir_gemm_nt_group_ws_needed": (Z, [C.POINTER(GemmNT), I, I]),
     "pir_split_bf16x3_batch": (I, [P, P, I, S]),
     "pir_split_bf16x3_taps": (I, [P, I, I, L, L, L, I, P, S]),
     "pir_conv3x3_x3": (I, [P, I, P, L, P, L, P, L, I, I, I, I, I, S]),

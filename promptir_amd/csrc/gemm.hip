@@ -1035,17 +1035,8 @@ extern "C" size_t pir_gemm_nt_ws_floats(int M1, int M2, int N, int O, int BR) {
   return (size_t)s * O * M1 * M2;
 }
 
-extern "C" int pir_gemm_nt(const pir_gemm_nt_t* a, pir_stream_t stream) {
-  PIR_CHECK_ARG(a && a->X && a->Y && a->G && a->ws);
-  PIR_CHECK_ARG(a->M1 > 0 && a->M2 > 0 && a->N > 0 && a->O1 > 0 && a->O2 > 0 && a->BR > 0);
-  const int O = a->O1 * a->O2;
-  PIR_CHECK_ARG(O <= 65535);
-  PIR_CHECK_ARG(a->H == 0 || (long)a->H * a->W == a->N);
-  NTParams p;
-  p.g = *a;
-  pir_gemm_nt_t& g = p.g;
-  // G^T[j][i] = sum_n Y[j][n] X[i][n]: the output strides are free, so put the larger extent on M1
-  // (tile rows) unless a tap shift pins the second operand.
+// the larger extent on the tile rows (free output strides), unless a tap shift pins the second operand
+static void nt_orient(pir_gemm_nt_t& g) {
   if (g.H == 0 && g.M2 > g.M1) {
     const float* t = g.X; g.X = g.Y; g.Y = t;
     long v;
@@ -1056,6 +1047,43 @@ extern "C" int pir_gemm_nt(const pir_gemm_nt_t* a, pir_stream_t stream) {
     v = g.g_si; g.g_si = g.g_sj; g.g_sj = v;
     int m = g.M1; g.M1 = g.M2; g.M2 = m;
   }
+}
+
+// split count launch_nt would use for this call (mirrors its decisions; 0 = invalid arguments)
+static int nt_splits_for(pir_gemm_nt_t g) {
+  if (!(g.X && g.Y && g.M1 > 0 && g.M2 > 0 && g.N > 0 && g.O1 > 0 && g.O2 > 0 && g.BR > 0)) return 0;
+  nt_orient(g);
+  auto al = [](const float* q, long s1, long s2, long sr, long ld) {
+    return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && s1 % 4 == 0 && s2 % 4 == 0 && sr % 4 == 0 && ld % 4 == 0;
+  };
+  const bool vec4 = g.H == 0 && g.N % 4 == 0 && al(g.X, g.x_s1, g.x_s2, g.x_sr, g.ldx) && al(g.Y, g.y_s1, g.y_s2, g.y_sr, g.ldy);
+  const bool x3 = vec4 && g_nt_x3 != 0;
+  const NTPlan pl = nt_plan(g.M1, g.M2, g.N, g.O1 * g.O2, g.BR, x3 ? X3_BK : NT_BK, x3, false);
+  if (x3 && g_nt_cfg < 0 && g_nt_splits == 0) {
+    g.ws_floats = (size_t)1 << 60;
+    const int xs = pir_nt_xp_splits(&g);
+    if (xs > 0) return xs;
+  }
+  return pl.splits;
+}
+
+// Workspace floats THIS call needs (its actual split count; pir_gemm_nt_ws_floats is the worst case over every plan).
+// Callers that give every call a workspace piece of its own (deferred reductions) size the pieces with it.
+extern "C" size_t pir_gemm_nt_ws_needed(const pir_gemm_nt_t* a) {
+  if (!a) return 0;
+  return (size_t)nt_splits_for(*a) * a->O1 * a->O2 * a->M1 * a->M2;
+}
+
+extern "C" int pir_gemm_nt(const pir_gemm_nt_t* a, pir_stream_t stream) {
+  PIR_CHECK_ARG(a && a->X && a->Y && a->G && a->ws);
+  PIR_CHECK_ARG(a->M1 > 0 && a->M2 > 0 && a->N > 0 && a->O1 > 0 && a->O2 > 0 && a->BR > 0);
+  const int O = a->O1 * a->O2;
+  PIR_CHECK_ARG(O <= 65535);
+  PIR_CHECK_ARG(a->H == 0 || (long)a->H * a->W == a->N);
+  NTParams p;
+  p.g = *a;
+  pir_gemm_nt_t& g = p.g;
+  nt_orient(g);   // G^T[j][i] = sum_n Y[j][n] X[i][n]: the output strides are free, so the larger extent goes on M1 (tile rows)
   return launch_nt(p, a->ws_floats, 0, 0L, (hipStream_t)stream);
 }
 
@@ -1064,43 +1092,33 @@ extern "C" int pir_gemm_nt(const pir_gemm_nt_t* a, pir_stream_t stream) {
 // tiles, every problem with its own workspace and its own (deferrable) second stage.  Problems the grouped kernel does
 // not serve (unaligned rows, different tile shapes, the "X private" shapes) are launched one by one: the results are
 // those of pir_gemm_nt either way, up to the order of the split-K sum.
-extern "C" int pir_gemm_nt_group(const pir_gemm_nt_t* probs, int n, pir_stream_t stream) {
-  PIR_CHECK_ARG(probs && n > 0 && n <= NT_GROUP_MAX);
-  hipStream_t s = (hipStream_t)stream;
+// plan of a grouped launch: fills grp (oriented problems, tile counts), tile shape and the common split count; false = not served
+static bool nt_group_plan(const pir_gemm_nt_t* probs, int n, NTGroup& grp, int& cfg, int& quad, long& sp) {
   auto al = [](const float* q, long s1, long s2, long sr, long ld) {
     return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && s1 % 4 == 0 && s2 % 4 == 0 && sr % 4 == 0 && ld % 4 == 0;
   };
-  NTGroup grp;
   grp.n = 0;
-  int cfg = -1, quad = -1;
+  cfg = -1; quad = -1;
   long tiles_total = 0, total_chunks = -1;
-  bool ok = n > 1 && g_nt_cfg < 0 && g_nt_splits == 0 && g_nt_x3 != 0;
-  for (int k = 0; k < n && ok; ++k) {
+  if (!(n > 1 && n <= NT_GROUP_MAX && g_nt_cfg < 0 && g_nt_splits == 0 && g_nt_x3 != 0)) return false;
+  for (int k = 0; k < n; ++k) {
     const pir_gemm_nt_t* a = &probs[k];
-    PIR_CHECK_ARG(a->X && a->Y && a->G && a->ws && a->M1 > 0 && a->M2 > 0 && a->N > 0 && a->BR > 0);
+    if (!(a->X && a->Y && a->M1 > 0 && a->M2 > 0 && a->N > 0 && a->BR > 0)) return false;
     NTParams& p = grp.p[k];
     p.g = *a;
     pir_gemm_nt_t& g = p.g;
-    if (g.O1 * g.O2 != 1 || g.H != 0) { ok = false; break; }
-    if (g.M2 > g.M1) {   // larger extent on the tile rows (as pir_gemm_nt)
-      const float* t = g.X; g.X = g.Y; g.Y = t;
-      long v;
-      v = g.x_sr; g.x_sr = g.y_sr; g.y_sr = v;
-      v = g.ldx; g.ldx = g.ldy; g.ldy = v;
-      v = g.g_si; g.g_si = g.g_sj; g.g_sj = v;
-      int m = g.M1; g.M1 = g.M2; g.M2 = m;
-    }
-    if (!(g.N % 4 == 0 && al(g.X, 0, 0, g.x_sr, g.ldx) && al(g.Y, 0, 0, g.y_sr, g.ldy))) { ok = false; break; }
-    int xs = 0;
-    { pir_gemm_nt_t probe = g; if (pir_nt_xp_splits(&probe) > 0) { ok = false; break; } (void)xs; }
+    if (g.O1 * g.O2 != 1 || g.H != 0) return false;
+    nt_orient(g);
+    if (!(g.N % 4 == 0 && al(g.X, 0, 0, g.x_sr, g.ldx) && al(g.Y, 0, 0, g.y_sr, g.ldy))) return false;
+    { pir_gemm_nt_t probe = g; probe.ws_floats = (size_t)1 << 60; if (pir_nt_xp_splits(&probe) > 0) return false; }
     const NTPlan pl = nt_plan(g.M1, g.M2, g.N, 1, g.BR, X3_BK, true, false);
     const int q = (g.N >= 1024 && pl.cfg != 1) ? 1 : 0;
-    if (pl.cfg != 2 && pl.cfg != 3) { ok = false; break; }
+    if (pl.cfg != 2 && pl.cfg != 3) return false;
     if (cfg < 0) { cfg = pl.cfg; quad = q; }
-    if (pl.cfg != cfg || q != quad) { ok = false; break; }
+    if (pl.cfg != cfg || q != quad) return false;
     const long chunks = (long)g.BR * pl.chunks_per_r;
     if (total_chunks < 0) total_chunks = chunks;
-    if (chunks != total_chunks || chunks >= 2147483647L) { ok = false; break; }
+    if (chunks != total_chunks || chunks >= 2147483647L) return false;
     p.chunks_per_r = pl.chunks_per_r;
     p.tap_sign = 0;
     p.magic_w = pir_magic(1u);
@@ -1108,19 +1126,37 @@ extern "C" int pir_gemm_nt_group(const pir_gemm_nt_t* probs, int n, pir_stream_t
     tiles_total += grp.ntiles[k];
     grp.n = k + 1;
   }
-  if (!ok) {
+  // one split count for the launch: all workgroups resident at once (as nt_plan), at least 128 pixels per split
+  long want = (long)g_nt_want_half * PIR_NUM_CU / (2 * tiles_total);
+  if (want < 1) want = 1;
+  const long max_by_work = total_chunks / (128 / X3_BK) > 0 ? total_chunks / (128 / X3_BK) : 1;
+  sp = want < max_by_work ? want : max_by_work;
+  if (sp > 1024) sp = 1024;
+  return true;
+}
+
+// workspace floats problem k of this group needs (its actual split count)
+extern "C" size_t pir_gemm_nt_group_ws_needed(const pir_gemm_nt_t* probs, int n, int k) {
+  if (!probs || k < 0 || k >= n) return 0;
+  NTGroup grp; int cfg, quad; long sp;
+  if (nt_group_plan(probs, n, grp, cfg, quad, sp)) return (size_t)sp * probs[k].M1 * probs[k].M2;
+  return pir_gemm_nt_ws_needed(&probs[k]);
+}
+
+extern "C" int pir_gemm_nt_group(const pir_gemm_nt_t* probs, int n, pir_stream_t stream) {
+  PIR_CHECK_ARG(probs && n > 0 && n <= NT_GROUP_MAX);
+  hipStream_t s = (hipStream_t)stream;
+  for (int k = 0; k < n; ++k) PIR_CHECK_ARG(probs[k].X && probs[k].Y && probs[k].G && probs[k].ws);
+  NTGroup grp;
+  int cfg = -1, quad = -1;
+  long sp = 1;
+  if (!nt_group_plan(probs, n, grp, cfg, quad, sp)) {
     for (int k = 0; k < n; ++k) {
       const int st = pir_gemm_nt(&probs[k], stream);
       if (st) return st;
     }
     return PIR_OK;
   }
-  // one split count for the launch: all workgroups resident at once (as nt_plan), at least 128 pixels per split
-  long want = (long)g_nt_want_half * PIR_NUM_CU / (2 * tiles_total);
-  if (want < 1) want = 1;
-  const long max_by_work = total_chunks / (128 / X3_BK) > 0 ? total_chunks / (128 / X3_BK) : 1;
-  long sp = want < max_by_work ? want : max_by_work;
-  if (sp > 1024) sp = 1024;
   long blocks = 0;
   for (int k = 0; k < grp.n; ++k) {
     NTParams& p = grp.p[k];

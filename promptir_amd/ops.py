@@ -124,7 +124,7 @@ class _TimedLib:
 
     def __getattr__(self, name):
         fn = getattr(self._raw, name)
-        if self.records is None or name.endswith("_floats") or name.endswith("_plan"):   # host-only queries
+        if self.records is None or name.endswith("_floats") or name.endswith("_plan") or name.endswith("_needed"):   # host-only queries
             return fn
 
         def timed(*args):
@@ -300,7 +300,7 @@ def _arena_take(nfloats: int, device: torch.device, st: int) -> torch.Tensor:
             a["off"] = 0
             continue
         # chunks are never freed or replaced (captured graphs hold their addresses); sized for a block's worth of partials
-        a["bufs"].append(torch.empty(max(n, 1 << 26), dtype=torch.float32, device=device))
+        a["bufs"].append(torch.empty(max(n, 1 << 24), dtype=torch.float32, device=device))
 
 
 class deferred_reductions:
@@ -441,8 +441,6 @@ def gemm_nt(X: torch.Tensor, x_off: int, x_str: Tuple[int, int, int], ldx: int,
             G: torch.Tensor, g_off: int, g_str: Tuple[int, int, int],
             M1: int, M2: int, N: int, O1: int, O2: int, BR: int,
             shift: Optional[Tuple[int, int, int, int]] = None, alpha: float = 1.0, accumulate: bool = False) -> None:
-    nws = lib.pir_gemm_nt_ws_floats(M1, M2, N, O1 * O2, BR)
-    ws = workspace(nws, X.device)
     g = _lib.GemmNT()
     g.X, g.x_s1, g.x_s2, g.x_sr, g.ldx = X.data_ptr() + 4 * x_off, x_str[0], x_str[1], x_str[2], ldx
     g.Y, g.y_s1, g.y_s2, g.y_sr, g.ldy = Y.data_ptr() + 4 * y_off, y_str[0], y_str[1], y_str[2], ldy
@@ -450,6 +448,11 @@ def gemm_nt(X: torch.Tensor, x_off: int, x_str: Tuple[int, int, int], ldx: int,
     g.M1, g.M2, g.N, g.O1, g.O2, g.BR = M1, M2, N, O1, O2, BR
     if shift is not None:
         g.shift_dh, g.shift_dw, g.H, g.W = shift
+    if _DEFER.get(_stream(), 0) > 0:    # a piece of its own until the flush: sized for THIS call's split count
+        nws = lib.pir_gemm_nt_ws_needed(C.byref(g))
+    else:                               # the one reused buffer: worst case over the plans
+        nws = lib.pir_gemm_nt_ws_floats(M1, M2, N, O1 * O2, BR)
+    ws = workspace(nws, X.device)
     g.ws, g.ws_floats = ws.data_ptr(), ws.numel()
     g.alpha, g.accumulate = alpha, int(accumulate)
     check(lib.pir_gemm_nt(C.byref(g), _stream()), "pir_gemm_nt")
@@ -462,21 +465,25 @@ NT_GROUP_MAX_HW = int(_os.environ.get("PIR_NT_GROUP_MAX_HW", "1024"))
 def conv1x1_wgrad_group(items) -> None:
     """[(dy, x, dw)]: dW_k = sum_b dy_k[b] x_k[b]^T for up to four 1x1 convolutions in ONE launch (pir_gemm_nt_group):
     the weight gradients of a block at the 32^2 / 16^2 levels, each of which alone has too few output tiles for the chip."""
+    if _DEFER.get(_stream(), 0) <= 0:
+        raise RuntimeError("conv1x1_wgrad_group: inside a deferred_reductions() scope only (one workspace piece per problem)")
     probs = (_lib.GemmNT * len(items))()
     keep = []
     for k, (dy, x, dw) in enumerate(items):
         dy, x = _planes(dy), _planes(x)
         b, cout, h, wd = dy.shape
         cin, hw = x.shape[1], h * wd
-        ws = workspace(lib.pir_gemm_nt_ws_floats(cout, cin, hw, 1, b), x.device)
         g = probs[k]
         g.X, g.x_s1, g.x_s2, g.x_sr, g.ldx = dy.data_ptr(), 0, 0, _bs(dy), hw
         g.Y, g.y_s1, g.y_s2, g.y_sr, g.ldy = x.data_ptr(), 0, 0, _bs(x), hw
         g.G, g.g_so, g.g_si, g.g_sj = dw.data_ptr(), 0, cin, 1
         g.M1, g.M2, g.N, g.O1, g.O2, g.BR = cout, cin, hw, 1, 1, b
-        g.ws, g.ws_floats = ws.data_ptr(), ws.numel()
         g.alpha, g.accumulate = 1.0, 0
-        keep += [dy, x, ws]
+        keep += [dy, x]
+    for k in range(len(items)):      # every problem's own piece, sized for the group's common split count
+        ws = workspace(lib.pir_gemm_nt_group_ws_needed(probs, len(items), k), items[k][0].device)
+        probs[k].ws, probs[k].ws_floats = ws.data_ptr(), ws.numel()
+        keep.append(ws)
     check(lib.pir_gemm_nt_group(probs, len(items), _stream()), "pir_gemm_nt_group")
 
 
@@ -644,6 +651,20 @@ def ln_conv1x1_forward(x: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, 
     return (y, mean, rstd) if stats else y
 
 
+def _wgrad_ln_ws(dy, x, b, cout, cin, hw) -> int:
+    """Workspace floats of conv1x1_wgrad_ln: inside a deferral scope the exact need of the split-K kernel it runs."""
+    if _DEFER.get(_stream(), 0) <= 0:
+        return lib.pir_gemm_nt_ws_floats(cout, cin, hw, 1, b)
+    g = _lib.GemmNT()
+    g.X, g.x_sr, g.ldx = dy.data_ptr(), _bs(dy), hw
+    g.Y, g.y_sr, g.ldy = x.data_ptr(), _bs(x), hw
+    g.M1, g.M2, g.N, g.O1, g.O2, g.BR = cout, cin, hw, 1, 1, b
+    need = lib.pir_gemm_nt_ws_needed(C.byref(g))
+    # the LayerNorm-on-load kernel serves shorter pixel ranges than the plain "X private" plan: one slice per CU, two
+    # for <= 4 row blocks (gemm_ntx.hip: xp_plan)
+    return max(need, (512 if cout <= 128 else 256) * cout * cin)
+
+
 def conv1x1_wgrad_ln(dy, x, mean, rstd, ln_w, ln_b, like, out=None):
     """dW = sum_b dy[b] LayerNorm(x[b])^T with the LayerNorm applied as the kernel stages x (pir_conv1x1_wgrad_ln); where
     that kernel does not serve the shape the normalised tensor is materialised first."""
@@ -651,7 +672,7 @@ def conv1x1_wgrad_ln(dy, x, mean, rstd, ln_w, ln_b, like, out=None):
     b, cout, h, wd = dy.shape
     cin = x.shape[1]
     dw = _grad_out(like, out)
-    ws = workspace(lib.pir_gemm_nt_ws_floats(cout, cin, h * wd, 1, b), x.device)
+    ws = workspace(_wgrad_ln_ws(dy, x, b, cout, cin, h * wd), x.device)
     st = lib.pir_conv1x1_wgrad_ln(dy.data_ptr(), _bs(dy), x.data_ptr(), _bs(x), mean.data_ptr(), rstd.data_ptr(),
                                   ln_w.data_ptr(), ln_b.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(),
                                   b, cout, cin, h * wd, _stream())
