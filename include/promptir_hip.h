@@ -388,6 +388,11 @@ int pir_reduce_partials(const float* parts, long stride, int S, float alpha, int
 int pir_reduce_defer(pir_stream_t stream, int on);
 int pir_reduce_flush(pir_stream_t stream);
 int pir_reduce_pending(pir_stream_t stream);
+/* Partial sets of more than `bytes` bytes (splits x elements x 4) are reduced at once even inside a deferral scope: right
+ * behind its producer a reduction reads the partial sums from cache, a deferred one from HBM.  Default 4 MiB; returns the
+ * limit in effect (bytes < 0: query only).  A caller that sizes its workspace pieces by the same rule may hand the
+ * reused buffer to the large ones. */
+long pir_reduce_defer_limit(long bytes);
 /* torch.optim.AdamW step (train.py:53: lr 2e-4, betas .9/.999, eps 1e-8, weight_decay 1e-2),
  * over a flat parameter / gradient / moment buffer.  `step` is the 1-based step count. */
 int pir_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long count,

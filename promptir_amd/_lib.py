@@ -115,6 +115,7 @@ SIGNATURES = {
     "pir_reduce_defer": (I, [S, I]),
     "pir_reduce_flush": (I, [S]),
     "pir_reduce_pending": (I, [S]),
+    "pir_reduce_defer_limit": (L, [L]),
     "pir_ln_conv1x1_fwd": (I, [P, L, P, P, P, I, P, L, P, P, I, I, I, I, S]),
     "pir_conv1x1_wgrad_ln": (I, [P, L, P, L, P, P, P, P, P, P, Z, I, I, I, I, S]),
     "pir_conv1x1_dgrad_ln_bwd": (I, [P, L, P, I, I, P, L, P, P, P, P, L, P, L, P, P, P, Z, I, I, I, S]),
@@ -143,7 +144,17 @@ def _load() -> C.CDLL:
     got = lib.pir_abi_version()
     if got != ABI_VERSION:
         raise HipLibraryError(f"ABI mismatch: library reports {got}, binding expects {ABI_VERSION}; rebuild")
+    raw_tune = lib.pir_tune_set
+
+    def tune_set(knob, value):      # every knob change is counted: host-side caches of "which shapes a kernel serves" key on it
+        KNOB_EPOCH[0] += 1
+        return raw_tune(knob, value)
+
+    lib.pir_tune_set = tune_set
     return lib
+
+
+KNOB_EPOCH = [0]
 
 
 lib = _load()

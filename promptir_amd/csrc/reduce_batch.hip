@@ -151,6 +151,11 @@ int launch_one(const ReduceDesc& d, hipStream_t s) {
 
 struct StreamQueue { bool defer = false; std::vector<ReduceDesc> q; };
 std::mutex g_mu;
+// Only SMALL partial sets are worth deferring: a reduction launched right behind its producer reads the partial sums from
+// cache, a deferred one reads them from HBM after a block's worth of other traffic.  Measured (round 4, same box): with
+// every split-K reduction deferred (~2 GB of partial tiles per part batch parked until the flush) the batch-32 step lost
+// 1 ms and the batch-8 step 2.7 ms; LayerNorm / depthwise / temperature partials are a few hundred KB.
+long g_defer_limit_bytes = 4L << 20;
 std::unordered_map<hipStream_t, StreamQueue> g_queues;
 
 int flush_locked(StreamQueue& sq, hipStream_t s) {
@@ -186,6 +191,7 @@ int submit(const ReduceDesc& d, hipStream_t s) {
   std::lock_guard<std::mutex> lock(g_mu);
   auto it = g_queues.find(s);
   if (it == g_queues.end() || !it->second.defer) return launch_one(d, s);
+  if ((long)d.S * d.stride * 4 > g_defer_limit_bytes) return launch_one(d, s);
   StreamQueue& sq = it->second;
   for (const ReduceDesc& q : sq.q)
     if (q.out == d.out || (d.out2 && (q.out == d.out2 || q.out2 == d.out2)) || (q.out2 && q.out2 == d.out)) {
@@ -231,6 +237,14 @@ extern "C" int pir_reduce_defer(pir_stream_t stream, int on) {
   std::lock_guard<std::mutex> lock(g_mu);
   g_queues[(hipStream_t)stream].defer = on != 0;
   return PIR_OK;
+}
+
+// partial sets larger than this many bytes are reduced at once even inside a deferral scope (default 4 MiB); returns the
+// limit in effect (bytes < 0: query only)
+extern "C" long pir_reduce_defer_limit(long bytes) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (bytes >= 0) g_defer_limit_bytes = bytes;
+  return g_defer_limit_bytes;
 }
 
 extern "C" int pir_reduce_pending(pir_stream_t stream) {

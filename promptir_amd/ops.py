@@ -261,14 +261,19 @@ _WS = {}
 _WS_RETIRED = []   # outgrown buffers stay alive: a captured graph may still hold their addresses
 
 
-def workspace(nfloats: int, device: torch.device, slot: str = "main") -> torch.Tensor:
+def workspace(nfloats: int, device: torch.device, slot: str = "main", own: bool = False) -> torch.Tensor:
     """Grow-only scratch buffer per (device, slot).  All kernels of one op are enqueued on the
     current stream in order, so one buffer per slot is race-free on a single stream.
     Inside a `deferred_reductions()` scope the partial sums a kernel leaves here are read only at the flush: every
     request then gets its own piece of a bump-allocated arena instead of the one reused buffer."""
     st = _stream()
+    # (large partial sets are reduced at once by the library even inside the scope - pir_reduce_defer_limit - and keep the
+    # reused, cache-resident buffer; `own`: the caller needs a piece nobody else gets before the flush regardless)
     if slot == "main" and _DEFER.get(st, 0) > 0:
-        return _arena_take(int(nfloats), device, st)
+        if own or 4 * int(nfloats) <= DEFER_LIMIT_BYTES:
+            _defer_switch(st, True)
+            return _arena_take(int(nfloats), device, st)
+        _defer_switch(st, False)      # the reduction that uses the reused buffer must run before the next call overwrites it
     key = (device.index, slot, st)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nfloats:
@@ -281,9 +286,20 @@ def workspace(nfloats: int, device: torch.device, slot: str = "main") -> torch.T
 
 # ---- deferred, batched second stages of the parameter-gradient reductions (csrc/reduce_batch.hip) ----------------
 DEFER_REDUCE = _os.environ.get("PIR_DEFER_REDUCE", "1") != "0"
+DEFER_LIMIT_BYTES = int(_os.environ.get("PIR_DEFER_LIMIT", str(4 << 20)))
+_lib.lib.pir_reduce_defer_limit(DEFER_LIMIT_BYTES)
 _DEFER = {}     # stream handle -> nesting depth of open deferral scopes
 _ARENAS = {}    # (device index, stream) -> {"bufs": [tensors], "cur": index, "off": floats used in bufs[cur]}
 _DEFER_KEEP = {}   # stream -> tensors that hold queued partial sums (kept alive until the flush)
+
+
+_DEFER_ON = {}   # stream -> what the library was last told (pir_reduce_defer)
+
+
+def _defer_switch(st: int, on: bool) -> None:
+    if _DEFER_ON.get(st, False) != on:
+        check(_lib.lib.pir_reduce_defer(st, int(on)), "pir_reduce_defer")
+        _DEFER_ON[st] = on
 
 
 def _arena_take(nfloats: int, device: torch.device, st: int) -> torch.Tensor:
@@ -316,7 +332,7 @@ class deferred_reductions:
             self.st = _stream()
             depth = _DEFER.get(self.st, 0)
             if depth == 0:
-                check(_lib.lib.pir_reduce_defer(self.st, 1), "pir_reduce_defer")
+                _defer_switch(self.st, True)
             _DEFER[self.st] = depth + 1
         return self
 
@@ -325,7 +341,7 @@ class deferred_reductions:
             depth = _DEFER[self.st] - 1
             _DEFER[self.st] = depth
             if depth == 0:
-                check(_lib.lib.pir_reduce_defer(self.st, 0), "pir_reduce_defer")
+                _defer_switch(self.st, False)
         return False
 
 
@@ -336,14 +352,14 @@ class immediate_reductions:
         self.st = _stream()
         self.depth = _DEFER.get(self.st, 0)
         if self.depth:
-            check(_lib.lib.pir_reduce_defer(self.st, 0), "pir_reduce_defer")
+            _defer_switch(self.st, False)
             _DEFER[self.st] = 0
         return self
 
     def __exit__(self, *exc):
         if self.depth:
             _DEFER[self.st] = self.depth
-            check(_lib.lib.pir_reduce_defer(self.st, 1), "pir_reduce_defer")
+            _defer_switch(self.st, True)
         return False
 
 
@@ -351,6 +367,7 @@ def keep_until_flush(t: torch.Tensor) -> torch.Tensor:
     """A tensor of partial sums allocated by the caller (not the arena) whose reduction may be queued."""
     st = _stream()
     if _DEFER.get(st, 0) > 0:
+        _defer_switch(st, True)
         _DEFER_KEEP.setdefault(st, []).append(t)
     return t
 
@@ -481,7 +498,7 @@ def conv1x1_wgrad_group(items) -> None:
         g.alpha, g.accumulate = 1.0, 0
         keep += [dy, x]
     for k in range(len(items)):      # every problem's own piece, sized for the group's common split count
-        ws = workspace(lib.pir_gemm_nt_group_ws_needed(probs, len(items), k), items[k][0].device)
+        ws = workspace(lib.pir_gemm_nt_group_ws_needed(probs, len(items), k), items[k][0].device, own=True)
         probs[k].ws, probs[k].ws_floats = ws.data_ptr(), ws.numel()
         keep.append(ws)
     check(lib.pir_gemm_nt_group(probs, len(items), _stream()), "pir_gemm_nt_group")
@@ -629,6 +646,11 @@ def conv1x1_forward(x: torch.Tensor, w: torch.Tensor, residual: Optional[torch.T
     return out
 
 
+_NOT_SERVED = {}   # (kernel, shape, alignment) -> True once the library answered 1000 ("shape not served"): the fused entry
+# points are tried once per shape; afterwards the caller goes straight to the unfused pair without allocating the fused
+# call's outputs first.  Tuning knobs that change what is served are set before the first call.
+
+
 def ln_conv1x1_forward(x: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, w: torch.Tensor, stats: bool = False):
     """y[b] = W LayerNorm_c(x[b]) with the channel LayerNorm applied on load (pir_ln_conv1x1_fwd): the normalised tensor
     is never written.  no_grad forward: nothing needs it afterwards; training (`stats`: returns (y, mean, rstd)): the weight
@@ -639,6 +661,9 @@ def ln_conv1x1_forward(x: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, 
     x = _planes(x)
     b, cin, h, wd = x.shape
     cout = w.shape[0]
+    skey = ("ln_fwd", _lib.KNOB_EPOCH[0], b, cout, cin, h * wd, bool(stats), _bs(x) % 4, x.data_ptr() % 16)
+    if _NOT_SERVED.get(skey):      # the library said 1000 for this shape before: no allocations, no weight split
+        return None
     a3, kp = _split_weight(w, dgrad=False)
     y = torch.empty((b, cout, h, wd), dtype=torch.float32, device=x.device)
     mean = torch.empty((b, h * wd), dtype=torch.float32, device=x.device) if stats else None
@@ -646,6 +671,7 @@ def ln_conv1x1_forward(x: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, 
     st = lib.pir_ln_conv1x1_fwd(x.data_ptr(), _bs(x), ln_w.data_ptr(), ln_b.data_ptr(), a3.data_ptr(), kp, y.data_ptr(),
                                 _bs(y), _p(mean), _p(rstd), b, cout, cin, h * wd, _stream())
     if st == 1000:
+        _NOT_SERVED[skey] = True
         return None
     check(st, "pir_ln_conv1x1_fwd")
     return (y, mean, rstd) if stats else y
@@ -797,6 +823,10 @@ def conv1x1_dgrad_ln_backward(dy, w, x, ln_w, mean, rstd, dweight=None, dbias=No
     if dres is not None:
         dres = _planes(dres)
     b, c, h, wd = x.shape
+    skey = ("dgrad_ln", _lib.KNOB_EPOCH[0], b, c, dy.shape[1], h * wd, _bs(x) % 4, _bs(dy) % 4, x.data_ptr() % 16, dy.data_ptr() % 16,
+            None if dres is None else (_bs(dres) % 4, dres.data_ptr() % 16), mean.data_ptr() % 16, rstd.data_ptr() % 16)
+    if _NOT_SERVED.get(skey):
+        return None
     a3, kp = _split_weight(w, dgrad=True)
     dx = torch.empty((b, c, h, wd), dtype=torch.float32, device=x.device)
     dweight, dbias = _grad_out(ln_w, dweight), _grad_out(ln_w, dbias)
@@ -806,6 +836,7 @@ def conv1x1_dgrad_ln_backward(dy, w, x, ln_w, mean, rstd, dweight=None, dbias=No
                                       _bs(dres) if dres is not None else 0, dx.data_ptr(), _bs(dx), dweight.data_ptr(),
                                       dbias.data_ptr(), ws.data_ptr(), ws.numel(), b, c, h * wd, _stream())
     if st == 1000:
+        _NOT_SERVED[skey] = True
         return None
     check(st, "pir_conv1x1_dgrad_ln_bwd")
     return dx, dweight, dbias
