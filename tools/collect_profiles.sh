@@ -23,6 +23,7 @@ STEPS=1 run pmc_fetch "$EAGER" --kernel-trace --pmc FETCH_SIZE
 STEPS=1 run pmc_write "$EAGER" --kernel-trace --pmc WRITE_SIZE
 cd "$ROOT"
 python3 tools/pmc_summary.py "$OUT" > "$OUT/summary.txt" 2> "$OUT/summary.err"
+python3 tools/step_roofline.py --top 80 > "$OUT/gemm_shape_roofline.txt" 2> "$OUT/gemm_shape_roofline.err"
 # keep the per-kernel statistics, drop the raw per-dispatch CSVs (tens of MB: gpurun merges at most 64 MiB back)
 for t in trace_eager trace_graph; do
   f=$(find "$OUT/$t" -name "*kernel_stats.csv" | head -1)

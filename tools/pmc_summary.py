@@ -106,8 +106,9 @@ for r in rows:
         name = "pir_gemm_nn"
     elif k.startswith("gemm_nn_x3_kernel"):
         name = "pir_conv3x3_x3"
-    elif k.startswith("gemm_nt_x3_kernel") or k.startswith("gemm_nt_xp_kernel") or k.startswith("nt_reduce"):
-        name = "pir_gemm_nt"
+    elif k.startswith("gemm_nt_x3_kernel") or k.startswith("gemm_nt_x3_group_kernel") or k.startswith("gemm_nt_xp_kernel") \
+            or k.startswith("nt_reduce") or k.startswith("reduce_one_kernel<3>") or k.startswith("reduce_one_kernel<4>"):
+        name = "pir_gemm_nt"     # split-K products and their second stages (reduce_batch.hip kinds 3, 4 = the nt forms)
     else:
         name = k.split("<")[0]
     a = fam.setdefault(name, {"launches": 0, "us": 0.0, "fetch_kb_raw": 0.0, "write_kb": 0.0, "mfma_cycles": 0.0, "cycles": 0.0})
@@ -140,9 +141,21 @@ if os.path.exists(log):
                      f"{steps_in_trace} steps = {per_step * steps_in_trace}: family classification is off")
         for a in summary.values():
             a["steps_in_trace"] = steps_in_trace
+# whole step: every kernel's calibrated bytes x launches over the steps in the trace
+steps_in_trace = next((a["steps_in_trace"] for a in summary.values() if "steps_in_trace" in a), None)
+tot_bytes = sum((2.0 * r["fetch_kb_raw"] + r["write_kb"]) * 1024 * r["launches"] for r in rows
+                if r["fetch_kb_raw"] is not None and r["write_kb"] is not None)
+step_bytes = tot_bytes / steps_in_trace if steps_in_trace else None
+for a in summary.values():
+    a["fetch_factor"] = 2.0
 json.dump({"source": "tools/collect_profiles.sh + tools/pmc_summary.py (rocprofv3 --pmc, separate passes, serialized eager bench)",
-           "note": "traffic = 2 x FETCH_SIZE (gfx950 wide-read correction; 4-byte-per-lane loads are uncalibrated) + WRITE_SIZE",
+           "note": "traffic = 2 x FETCH_SIZE + WRITE_SIZE; the factor 2 is calibrated for 4-, 8- and 16-byte-per-lane streaming "
+                   "reads and the 64-byte-per-row stage loads of the split-K kernels alike (profiles/r04_fetch_calibration.txt: "
+                   "FETCH_SIZE x 1024 / bytes = 0.500 for every pattern; WRITE_SIZE = 1.000)",
+           "step_bytes": step_bytes, "steps_in_trace": steps_in_trace,
            "families": summary}, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+if step_bytes:
+    print(f"\n# whole step: {step_bytes / 1e9:.1f} GB per step (2 x FETCH_SIZE + WRITE_SIZE over every kernel, {steps_in_trace} steps in the trace)")
 print("\n# families (time-weighted)")
 for name, a in sorted(summary.items(), key=lambda kv: -kv[1]["mean_us"] * kv[1]["launches_in_trace"]):
     print(f"{name:28s} launches {a['launches_in_trace']:6d} mean {a['mean_us']:8.1f} us  fetch {a['fetch_kb_per_launch_raw']:10.0f} KB raw  write {a['write_kb_per_launch']:10.0f} KB"

@@ -51,11 +51,14 @@ out["under_10us_ms_per_step"] = round(sum(sum(v for v in x if v < 10.0) for x in
 out["wall_ms_per_step"] = round(sum((st[-1][1] - st[0][0]) for st in steady) / n * 1e-6, 3)
 foreign = collections.Counter()
 byname = collections.Counter()
+tname = collections.Counter()
 for st in steady:
-    for _, _, name in st:
+    for s0, e0, name in st:
         byname[short(name).split("<")[0]] += 1
+        tname[short(name)] += (e0 - s0) * 1e-6
         if not library(name):
             foreign[short(name)] += 1
 out["non_library_kernels_per_step"] = {k: round(v / n, 2) for k, v in foreign.most_common()}
 out["launches_by_kernel_per_step"] = {k: round(v / n, 1) for k, v in byname.most_common(40)}
+out["kernel_ms_per_step_by_instantiation"] = {k: round(v / n, 3) for k, v in tname.most_common(45)}
 print(json.dumps(out, indent=1))

@@ -3,7 +3,9 @@
 with its shape, measured time, and the time its own roofline allows (bf16x3 MFMA ceiling and HBM ceiling).  "fl" rows are
 the input gradients fused with a LayerNorm backward (M = C, K = cout; bytes: dy, x, dres read, dx written), "lf" the forward
 1x1 convolutions with the LayerNorm applied on load (pir_ln_conv1x1_fwd), "wl" the weight gradients that normalise x on load
-(pir_conv1x1_wgrad_ln; M = cout, K = cin)."""
+(pir_conv1x1_wgrad_ln; M = cout, K = cin), "ng" the grouped weight gradients of a low-resolution block (pir_gemm_nt_group:
+M = sum of the problems' rows, K = the shared column count, bat = problems in the group), "cw" the dense 3x3 weight
+gradients (pir_conv3x3_wgrad).  Reductions queued inside a deferral scope are timed with the flush, not with the call."""
 import argparse
 import os
 import sys
@@ -35,6 +37,7 @@ shapes = []
 raw = ops.lib._raw
 orig_nn, orig_nt, orig_fl = raw.pir_gemm_nn, raw.pir_gemm_nt, raw.pir_conv1x1_dgrad_ln_bwd
 orig_lf, orig_wl = raw.pir_ln_conv1x1_fwd, raw.pir_conv1x1_wgrad_ln
+orig_ng, orig_cw = raw.pir_gemm_nt_group, raw.pir_conv3x3_wgrad
 
 
 class Spy:
@@ -60,6 +63,15 @@ class Spy:
             if st != 1000:
                 shapes.append((("wl", cout, cin, hw, b, 0, 0, 0), 2.0 * cout * cin * hw * b, 4.0 * b * hw * (cout + cin + 2)))
             return st
+        if self.kind == "ng":      # grouped weight gradients of a low-resolution block: one row per group
+            ps = list(a[0])[:a[1]]
+            key = ("ng", sum(q.M1 for q in ps), ps[0].M2 if ps[0].M2 <= ps[0].M1 else ps[0].M1, ps[0].N, len(ps), ps[0].BR, 0, 0)
+            shapes.append((key, sum(2.0 * q.M1 * q.M2 * q.N * q.BR for q in ps), sum(4.0 * q.BR * (q.M1 + q.M2) * q.N for q in ps)))
+            return self.fn(*a)
+        if self.kind == "cw":      # dense 3x3 weight gradient
+            b, cout, cin, h, w = a[5:10]
+            shapes.append((("cw", cout, cin, h * w, b, 0, 0, 0), 2.0 * 9 * cout * cin * h * w * b, 4.0 * b * h * w * (cout + cin)))
+            return self.fn(*a)
         g = a[0]._obj
         if self.kind == "nn":
             key = ("nn", g.M, g.K, g.N, g.O1 * g.O2, bool(g.R), bool(g.A3), int(g.a_sm == 1))
@@ -76,17 +88,20 @@ class Spy:
 
 raw.pir_gemm_nn, raw.pir_gemm_nt, raw.pir_conv1x1_dgrad_ln_bwd = Spy(orig_nn, "nn"), Spy(orig_nt, "nt"), Spy(orig_fl, "fl")
 raw.pir_ln_conv1x1_fwd, raw.pir_conv1x1_wgrad_ln = Spy(orig_lf, "lf"), Spy(orig_wl, "wl")
+raw.pir_gemm_nt_group, raw.pir_conv3x3_wgrad = Spy(orig_ng, "ng"), Spy(orig_cw, "cw")
 ops.lib.start_timing()
 tr.train_step(x, t)
-recs = [r for r in ops.lib.stop_timing() if r[0] in ("pir_gemm_nn", "pir_gemm_nt", "pir_conv1x1_dgrad_ln_bwd", "pir_ln_conv1x1_fwd", "pir_conv1x1_wgrad_ln")]
+recs = [r for r in ops.lib.stop_timing() if r[0].split("@")[0] in ("pir_gemm_nn", "pir_gemm_nt", "pir_conv1x1_dgrad_ln_bwd", "pir_ln_conv1x1_fwd",
+                                                                     "pir_conv1x1_wgrad_ln", "pir_gemm_nt_group", "pir_conv3x3_wgrad")]
 raw.pir_gemm_nn, raw.pir_gemm_nt, raw.pir_conv1x1_dgrad_ln_bwd = orig_nn, orig_nt, orig_fl
 raw.pir_ln_conv1x1_fwd, raw.pir_conv1x1_wgrad_ln = orig_lf, orig_wl
+raw.pir_gemm_nt_group, raw.pir_conv3x3_wgrad = orig_ng, orig_cw
 assert len(recs) == len(shapes), (len(recs), len(shapes))
 agg = {}
 for (name, sec, _, _), (key, flops, byts) in zip(recs, shapes):
     a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
     a[0] += 1; a[1] += sec; a[2] += flops; a[3] += byts
-tot = {"nn": [0.0, 0.0], "nt": [0.0, 0.0], "fl": [0.0, 0.0], "lf": [0.0, 0.0], "wl": [0.0, 0.0]}
+tot = {"nn": [0.0, 0.0], "nt": [0.0, 0.0], "fl": [0.0, 0.0], "lf": [0.0, 0.0], "wl": [0.0, 0.0], "ng": [0.0, 0.0], "cw": [0.0, 0.0]}
 print(f"{'kind':3} {'M':>5} {'K':>5} {'N':>6} {'bat':>4} R A3 mf | calls  time_us  bound_us  mfma_us  hbm_us  eff")
 rows = []
 for key, (calls, sec, flops, byts) in agg.items():
