@@ -30,6 +30,7 @@ constexpr bool PIN_SCHED = PIR_PIN_SCHED;
 int g_nn_cfg = -1, g_nt_cfg = -1, g_nt_splits = 0, g_nn_x3 = -1, g_nt_x3 = -1;
 int g_nt_want_half = 5;   // knob 19: split-K workgroups per CU aimed at, in halves (bench sweep with two part-batch streams:
                           // 2: 100.5 ms, 4: 99.4, 5: 99.4, 6: 99.7-100.3, 8: 101.0, 12: 102.2; one stream: 6 beats 4 by 0.5 ms)
+int g_nt_tile96 = 1;  // knob 33: 96 x 96 three-wave tile for outputs of at most 96 x 96 (0: the 128 x 96 tile)
 int g_nt_quad = -1;   // knob 14: gemm_nt_x3 four-lanes-per-row stage loads (-1 automatic, 0 never, 1 always)
 
 __device__ __forceinline__ int c_row(int reg, int lane) { return pir_c_row(reg, lane); }
@@ -838,6 +839,11 @@ NTPlan nt_plan(int M1, int M2, int N, int O, int BR, int bk = NT_BK, bool wide_o
     pl.bn = c == 0 || c == 1 ? 64 : (c == 2 || c == 4 ? 96 : 128);
   } else if (M1 <= 64 && M2 <= 64) { pl.cfg = 0; pl.bm = 64; pl.bn = 64; }
   else if (M2 <= 64) { pl.cfg = 1; pl.bm = 128; pl.bn = 64; }
+  else if (bk == X3_BK && !taps && g_nt_tile96 && M1 <= 96 && M2 <= 96) {
+    // 96 x 96 outputs (the per-image gram and dW_eff of the 96-channel levels, net/model.py:129,133 and adjoint): three
+    // waves, no padded rows (the 128 x 96 tile loaded, split and multiplied 32 rows of nothing: a quarter of its work)
+    pl.cfg = 7; pl.bm = 96; pl.bn = 96;
+  }
   else {
     // (eight-wave 256 x 96 / 256 x 128 tiles exist behind knob 1 = 4 / 5: measured slower at every level, round 3)
     const long pad96 = pir_cdiv(M2, 96) * 96, pad128 = pir_cdiv(M2, 128) * 128;
@@ -908,6 +914,7 @@ int launch_nt(NTParams& p, size_t ws_floats, int tap_sign, long g_st, hipStream_
       case 2: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 3, 4, 1, false, true>), grid, dim3(256), 0, s, p); break;
       case 4: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 3, 8, 1, false, true>), grid, dim3(512), 0, s, p); break;   // 256 x 96
       case 5: hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2, 4, 2, false, true>), grid, dim3(512), 0, s, p); break;   // 256 x 128
+      case 7: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 3, 3, 1, false, true>), grid, dim3(192), 0, s, p); break;   // 96 x 96
       default: hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2, 2, 2, false, true>), grid, dim3(256), 0, s, p); break;
     }
   } else if (x3) {
@@ -917,6 +924,7 @@ int launch_nt(NTParams& p, size_t ws_floats, int tap_sign, long g_st, hipStream_
       case 2: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 3, 4, 1>), grid, dim3(256), 0, s, p); break;   // 128 x 96
       case 4: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 3, 8, 1>), grid, dim3(512), 0, s, p); break;   // 256 x 96
       case 5: hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2, 4, 2>), grid, dim3(512), 0, s, p); break;   // 256 x 128
+      case 7: hipLaunchKernelGGL((gemm_nt_x3_kernel<1, 3, 3, 1>), grid, dim3(192), 0, s, p); break;   // 96 x 96
       default: hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p); break;  // 128 x 128
     }
   } else {
@@ -956,6 +964,7 @@ extern "C" int pir_tune_set(int knob, int value) {
     case 8: case 9: case 10: return pir_stencil_wave_tune(knob, value);
     case 13: case 16: return pir_ln_tune(knob, value);
     case 14: g_nt_quad = value; return PIR_OK;
+    case 33: g_nt_tile96 = value; return PIR_OK;
     case 19: g_nt_want_half = value; return PIR_OK;
     case 20: return pir_nn_res_tune(knob, value);
     case 21: case 22: case 23: case 24: return pir_nn_res_tune2(knob, value);
