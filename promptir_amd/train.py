@@ -243,6 +243,7 @@ class DataParallelTrainer:
         if micro_streams is None:   # part streams only pay inside the graph (eagerly the extra launches bind the CPU)
             micro_streams = int(os.environ.get("PIR_MICRO_STREAMS", "2" if self.graph else "1"))
         self.micro_streams = max(1, micro_streams) if self.opt.param.is_cuda else 1
+        self.min_part = max(1, int(os.environ.get("PIR_MIN_PART", "4")))
         self._split_sig = None
         self._seg_state = None
         # backward in three segments with the gradient all-reduce of each finished range overlapping the next segment.
@@ -315,7 +316,7 @@ class DataParallelTrainer:
 
     def _fwd_bwd_parts(self, degrad_patch: torch.Tensor, clean_patch: torch.Tensor, two_streams: bool) -> torch.Tensor:
         b = degrad_patch.shape[0]
-        n = min(self.micro_streams, max(1, b // 4))      # parts of at least four samples
+        n = min(self.micro_streams, max(1, b // self.min_part))      # parts of at least `min_part` (four) samples
         if not (two_streams and n > 1):
             loss, seed = self._part_loss(self.net(degrad_patch), clean_patch, 1.0)
             loss.backward(gradient=seed)
@@ -357,7 +358,7 @@ class DataParallelTrainer:
         return self.opt.stages is not None and len(self.opt.stages) == 3 and hasattr(self.net, "encode_levels")
 
     def _parts(self, b: int):
-        n = min(self.micro_streams, max(1, b // 4))      # parts of at least four samples
+        n = min(self.micro_streams, max(1, b // self.min_part))      # parts of at least `min_part` (four) samples
         return n, [b * i // n for i in range(n + 1)]
 
     def _fork(self, n: int, device):
