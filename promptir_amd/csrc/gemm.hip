@@ -30,6 +30,7 @@ constexpr bool PIN_SCHED = PIR_PIN_SCHED;
 int g_nn_cfg = -1, g_nt_cfg = -1, g_nt_splits = 0, g_nn_x3 = -1, g_nt_x3 = -1;
 int g_nt_want_half = 5;   // knob 19: split-K workgroups per CU aimed at, in halves (bench sweep with two part-batch streams:
                           // 2: 100.5 ms, 4: 99.4, 5: 99.4, 6: 99.7-100.3, 8: 101.0, 12: 102.2; one stream: 6 beats 4 by 0.5 ms)
+int g_nt_group_wide = 1;   // knob 34: 128 x 192 tiles in the grouped low-resolution weight gradients (0: the single launches' tiles)
 int g_nt_tile96 = 0;  // knob 33: 96 x 96 three-wave tile for outputs of at most 96 x 96 (measured neutral in the step, round 4: off; 0 = the 128 x 96 tile)
 int g_nt_quad = -1;   // knob 14: gemm_nt_x3 four-lanes-per-row stage loads (-1 automatic, 0 never, 1 always)
 
@@ -802,8 +803,9 @@ struct NTGroup {
   int n;
 };
 
+// (the 128 x 192 tile: one wave = 32 rows x 192 columns, 96 accumulator registers, two workgroups per CU)
 template <int TM, int TN, int WM, int WN, bool QUAD>
-__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(3)))
+__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(TM * TN >= 6 ? 2 : 3)))
 void gemm_nt_x3_group_kernel(NTGroup grp) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   __shared__ pir_bf16x8 smem[2 * 3 * (2 * (BM + 4) + 2 * (BN + 4))];
@@ -965,6 +967,7 @@ extern "C" int pir_tune_set(int knob, int value) {
     case 13: case 16: return pir_ln_tune(knob, value);
     case 14: g_nt_quad = value; return PIR_OK;
     case 33: g_nt_tile96 = value; return PIR_OK;
+    case 34: g_nt_group_wide = value; return PIR_OK;
     case 19: g_nt_want_half = value; return PIR_OK;
     case 20: return pir_nn_res_tune(knob, value);
     case 21: case 22: case 23: case 24: return pir_nn_res_tune2(knob, value);
@@ -1120,9 +1123,13 @@ static bool nt_group_plan(const pir_gemm_nt_t* probs, int n, NTGroup& grp, int& 
     nt_orient(g);
     if (!(g.N % 4 == 0 && al(g.X, 0, 0, g.x_sr, g.ldx) && al(g.Y, 0, 0, g.y_sr, g.ldy))) return false;
     { pir_gemm_nt_t probe = g; probe.ws_floats = (size_t)1 << 60; if (pir_nt_xp_splits(&probe) > 0) return false; }
-    const NTPlan pl = nt_plan(g.M1, g.M2, g.N, 1, g.BR, X3_BK, true, false);
+    NTPlan pl = nt_plan(g.M1, g.M2, g.N, 1, g.BR, X3_BK, true, false);
     const int q = (g.N >= 1024 && pl.cfg != 1) ? 1 : 0;
     if (pl.cfg != 2 && pl.cfg != 3) return false;
+    // 128 x 192 tiles where every problem's columns come in 192s (the 192- and 384-channel levels): the conversion work
+    // per MFMA of the 128 x 96 tile (VALU active 0.45 beside MFMA busy 0.39, profiles/r04_pmc_summary.txt) drops by a
+    // third - each staged row meets twice as many columns
+    if (g_nt_group_wide && g.M2 % 192 == 0) { pl.cfg = 8; pl.bm = 128; pl.bn = 192; }
     if (cfg < 0) { cfg = pl.cfg; quad = q; }
     if (pl.cfg != cfg || q != quad) return false;
     const long chunks = (long)g.BR * pl.chunks_per_r;
@@ -1176,7 +1183,9 @@ extern "C" int pir_gemm_nt_group(const pir_gemm_nt_t* probs, int n, pir_stream_t
   }
   for (int k = grp.n; k <= NT_GROUP_MAX; ++k) grp.first[k] = (int)blocks;
   const dim3 grid((unsigned)blocks), block(256);
-  if (cfg == 2 && quad) hipLaunchKernelGGL((gemm_nt_x3_group_kernel<1, 3, 4, 1, true>), grid, block, 0, s, grp);
+  if (cfg == 8 && quad) hipLaunchKernelGGL((gemm_nt_x3_group_kernel<1, 6, 4, 1, true>), grid, block, 0, s, grp);
+  else if (cfg == 8) hipLaunchKernelGGL((gemm_nt_x3_group_kernel<1, 6, 4, 1, false>), grid, block, 0, s, grp);
+  else if (cfg == 2 && quad) hipLaunchKernelGGL((gemm_nt_x3_group_kernel<1, 3, 4, 1, true>), grid, block, 0, s, grp);
   else if (cfg == 2) hipLaunchKernelGGL((gemm_nt_x3_group_kernel<1, 3, 4, 1, false>), grid, block, 0, s, grp);
   else if (quad) hipLaunchKernelGGL((gemm_nt_x3_group_kernel<2, 2, 2, 2, true>), grid, block, 0, s, grp);
   else hipLaunchKernelGGL((gemm_nt_x3_group_kernel<2, 2, 2, 2, false>), grid, block, 0, s, grp);
