@@ -297,6 +297,19 @@ int pir_pixel_unshuffle2(const float* x, long x_bs, float* y, long y_bs, int B, 
 int pir_pixel_shuffle2(const float* x, long x_bs, float* y, long y_bs, int B, int C, int H, int W,
                        pir_stream_t stream);
 
+/* ------------------------------------------------------------------ GDFN forward without h0 (gdfn_fused.hip)
+ * g = gelu_erf(dw3x3(W_in LN(x))[:hid]) * dw3x3(W_in LN(x))[hid:]   (FeedForward behind norm2, net/model.py:94-97,195)
+ * in two launches that never write the 2 hid-channel tensor between project_in and the depthwise convolution: the
+ * channel LayerNorm + bf16x3 split of x into MFMA fragments (6 bytes per element, into `ws`), then per (image, 32 gate
+ * pairs) a walk down the image rows that multiplies, filters (register-resident pending rows), gates and stores.
+ * w3: pir_split_bf16x3 pieces of W_in [2 hid][C] (kp = C); wd: depthwise weights [2 hid][9]; mean / rstd: optional
+ * [B][HW] outputs.  Served: C = 48 or 96, W = 64 or 128, WithBias LayerNorm, no convolution bias; 1000 otherwise
+ * (nothing launched: the caller runs pir_ln_conv1x1_fwd / pir_layernorm_fwd + pir_gemm_nn, then pir_dwconv3x3_gate). */
+size_t pir_gdfn_fused_ws_bytes(int B, int C, int H, int W);
+int pir_gdfn_fused_fwd(const float* x, long x_bs, const float* ln_w, const float* ln_b, const void* w3, int kp,
+                       const float* wd, float* g, long g_bs, void* ws, size_t ws_bytes, float* mean, float* rstd,
+                       int B, int C, int hid, int H, int W, pir_stream_t stream);
+
 /* ------------------------------------------------------------------ PromptGenBlock (net/model.py:226-235)
  * emb = mean over pixels (:228) */
 int pir_spatial_mean(const float* x, long x_bs, float* out, int B, int C, int HW, pir_stream_t stream);

@@ -85,6 +85,8 @@ SIGNATURES = {
     "pir_dwconv3x3_bwd": (I, [P, L, P, L, P, P, L, P, P, Z, I, I, I, I, S]),
     "pir_gdfn_dwconv_bwd_ws_floats": (Z, [I, I, I, I]),
     "pir_gdfn_dwconv_bwd": (I, [P, L, P, P, L, P, L, P, P, Z, I, I, I, I, S]),
+    "pir_gdfn_fused_ws_bytes": (Z, [I, I, I, I]),
+    "pir_gdfn_fused_fwd": (I, [P, L, P, P, P, I, P, P, L, P, Z, P, P, I, I, I, I, I, S]),
     "pir_row_sumsq": (I, [P, L, P, I, I, I, S]),
     "pir_mdta_softmax_fwd": (I, [P, P, I, P, P, I, I, I, S]),
     "pir_mdta_softmax_bwd": (I, [P, P, P, P, I, P, P, P, P, P, I, I, I, S]),

@@ -1,0 +1,248 @@
+// GDFN forward without its 2 x hid-channel intermediate in memory (gfx950):
+//
+//     g = gelu_erf(dw3x3(W_in LN(x))[:hid]) * dw3x3(W_in LN(x))[hid:]          net/model.py:94-97 behind :195
+//
+// The unfused forward writes h0 = W_in LN(x) (2 hid = 510 planes at C = 96) and reads it back for the depthwise stencil:
+// 1020 of the block's ~3260 forward floats per pixel.  Here h0 only ever exists as MFMA accumulators:
+//
+//  pass 1, pir-internal (ln_split_rows_kernel): the channel LayerNorm (:60-63) of every pixel, split ONCE into the
+//      three bf16 pieces and stored as ready-made MFMA fragments (6 bytes per element; one 16-byte unit = 8 channels
+//      of one pixel), laid out so that a wave's fragment of (image row, 32-pixel block, k-step, piece) is 1 KB contiguous;
+//  pass 2 (gdfn_fused_kernel): a workgroup = one image x 32 gate pairs (64 rows of W_in: 32 of the first half and their
+//      32 partners of the second half, resident in LDS as bf16x3), NWV waves side by side covering the image row (one
+//      32-pixel block each), walking DOWN the rows.  Per row a wave multiplies its pixel fragments with the 64 weight
+//      rows - as D = pixels x channels, so that a lane ends up with ONE channel (lane & 31) of each half and 16 pixels
+//      of it (4 runs of 4 consecutive pixels): the depthwise taps are then 9 + 9 per-lane registers, horizontal
+//      neighbours are mostly the lane's own registers (run ends: the partner lane half; block ends: the neighbouring
+//      wave through a 1 KB LDS exchange), and vertical neighbours never exist at once - each arriving row adds its three
+//      horizontally filtered contributions into the two pending output rows (out[r-1] += w[2] * row r, out[r] += w[1],
+//      out[r+1] = w[0]).  A finished row goes through the gate (libm erff, as the unfused forward) and leaves as
+//      16-byte stores.  Every input row's product is computed once: no halo recompute.
+// The normalised, split activations are re-read by the ceil(hid / 32) workgroups of an image (from L2); h0 is never
+// written or read.  Served: W = 128 or 64 (4 or 2 waves per row), C = 48 or 96, bias-free, WithBias LayerNorm.
+#include "gemm_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------------------
+// pass 1: LayerNorm + bf16x3 split into fragment order.  One thread per pixel; the C channel values live in registers.
+// unit index of (image b, row y, block blk, k-step ks, piece, lane): ((((b H + y) NB + blk) KS + ks) 3 + piece) 64 + lane
+template <int C>
+__global__ __launch_bounds__(256) void ln_split_rows_kernel(const float* __restrict__ x, long x_bs, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16x8* __restrict__ out,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            int H, int W, int B) {
+  constexpr int KS = C / 16;
+  const long HW = (long)H * W;
+  const long pix = blockIdx.x * 256L + threadIdx.x;
+  if (pix >= (long)B * HW) return;
+  const int b = (int)(pix / HW);
+  const long p = pix - (long)b * HW;
+  const int y = (int)(p / W), xx = (int)(p - (long)y * W);
+  const float* __restrict__ src = x + (long)b * x_bs + p;
+  float v[C];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) { v[c] = src[(long)c * HW]; s += v[c]; }
+  const float mu = s / (float)C;
+  float s2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) { v[c] -= mu; s2 += v[c] * v[c]; }
+  const float rstd = 1.f / sqrtf(s2 / (float)C + 1e-5f);      // biased variance, eps inside the root (net/model.py:62-63)
+  if (mean_out) { mean_out[pix] = mu; rstd_out[pix] = rstd; }
+  const int NB = W / 32, blk = xx / 32, r = xx & 31;
+  bf16x8* __restrict__ dst = out + ((((long)b * H + y) * NB + blk) * KS) * 3 * 64;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = 16 * ks + 8 * h + e;
+        f[e] = v[c] * rstd * gamma[c] + beta[c];
+      }
+      const pir_frag3 fr = pir_split8(f);
+      bf16x8* u = dst + (long)ks * 3 * 64 + 32 * h + r;
+      u[0] = fr.hi; u[64] = fr.mid; u[128] = fr.lo;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct FusedArgs {
+  const bf16x8* xn3;          // pass-1 fragments
+  const bf16x8* w3;           // pir_split_bf16x3 pieces of W_in: unit ((part KS + ks) M + m) 2 + h, M = 2 hid
+  const float* wd;            // depthwise weights [2 hid][9]
+  float* g; long g_bs;        // [B][hid][H][W]
+  int hid, H, W;
+};
+
+__device__ __forceinline__ float gelu_erf_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+
+// NWV = W / 32 waves per workgroup, KS = C / 16
+template <int KS, int NWV>
+__global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(1)))
+void gdfn_fused_kernel(FusedArgs a) {
+  constexpr int T = NWV * 64;
+  constexpr int PUNITS = 3 * KS * 2 * 64;                 // weight panel: [piece][ks][h][64 rows]
+  __shared__ bf16x8 panel[PUNITS];
+  __shared__ float edge[2][2][2][NWV][32];                // [row parity][half nb][side: 0 = first pixel, 1 = last pixel][wave][channel]
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, cl = lane & 31;
+  const int q = blockIdx.x, b = blockIdx.y;
+  const int hid = a.hid, H = a.H, W = a.W, M = 2 * hid;
+  const int npairs = hid - 32 * q < 32 ? hid - 32 * q : 32;
+
+  // ---- weight panel: rows 0..31 = channels 32 q + i of the first half, rows 32..63 = their partners hid + 32 q + i
+  for (int u = tid; u < PUNITS; u += T) {
+    const int row = u & 63, hh = (u >> 6) & 1, rest = u >> 7;      // rest = piece * KS + ks
+    const int i = row & 31;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+    if (i < npairs) {
+      const int m = (row < 32 ? 0 : hid) + 32 * q + i;
+      v = a.w3[((long)rest * M + m) * 2 + hh];
+    }
+    panel[u] = v;
+  }
+  // ---- this lane's channel pair and its depthwise taps
+  const bool live = cl < npairs;
+  const int c1 = 32 * q + (live ? cl : 0), c2 = hid + c1;
+  float t1[9], t2[9];
+#pragma unroll
+  for (int e = 0; e < 9; ++e) { t1[e] = live ? a.wd[c1 * 9 + e] : 0.f; t2[e] = live ? a.wd[c2 * 9 + e] : 0.f; }
+  __syncthreads();
+
+  const bf16x8* __restrict__ xbase = a.xn3 + ((long)b * H * NWV + wid) * KS * 3 * 64 + lane;
+  const long row_units = (long)NWV * KS * 3 * 64;
+  float* __restrict__ gout = a.g + (long)b * a.g_bs + (long)c1 * H * W + 32 * wid + 4 * h;
+
+  bf16x8 cur[KS][3], nxt[KS][3];
+  auto load_row = [&](int r, bf16x8 (&f)[KS][3]) {
+    const bf16x8* __restrict__ p = xbase + (long)r * row_units;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) f[ks][pc] = p[(ks * 3 + pc) * 64];
+  };
+  load_row(0, cur);
+
+  // pending output rows: acc1 -> out[r - 1] once row r's bottom taps are in, acc2 -> out[r]
+  float acc1[2][16], acc2[2][16];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int p = 0; p < 16; ++p) { acc1[nb][p] = 0.f; acc2[nb][p] = 0.f; }
+
+  for (int r = 0; r <= H; ++r) {
+    const bool have = r < H;                                 // row H is the flush iteration: no input, out[H - 1] leaves
+    if (r + 1 < H) load_row(r + 1, nxt);
+    f32x16 d[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int p = 0; p < 16; ++p) d[nb][p] = 0.f;
+    if (have) {
+      const bf16x8* wp = panel + h * 64 + cl + (r >> 30);    // opaque zero: keeps the panel reads inside the loop
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const bf16x8 bh = wp[((0 * KS + ks) * 2) * 64 + nb * 32], bm = wp[((1 * KS + ks) * 2) * 64 + nb * 32],
+                       bl = wp[((2 * KS + ks) * 2) * 64 + nb * 32];
+          d[nb] = pir_mfma_x3(cur[ks][0], cur[ks][1], cur[ks][2], bh, bm, bl, d[nb]);      // D[pixel][channel]
+        }
+    }
+    // ---- block-edge pixels of the new row for the neighbouring waves (pixel 0: lane half 0, register 0; pixel 31: half 1, register 15)
+    const int par = r & 1;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) edge[par][nb][h][wid][cl] = h == 0 ? d[nb][0] : d[nb][15];
+    __syncthreads();
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const float (&tp)[9] = nb == 0 ? t1 : t2;
+      // run ends from the partner lane half
+      float rf[4], rl[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        rf[j] = __shfl_xor(d[nb][4 * j], 32, 64);
+        rl[j] = __shfl_xor(d[nb][4 * j + 3], 32, 64);
+      }
+      // block ends from the neighbouring waves (zero padding at the image border)
+      const float eL = (h == 0 && wid > 0) ? edge[par][nb][1][wid > 0 ? wid - 1 : 0][cl] : 0.f;          // pixel -1
+      const float eR = (h == 1 && wid + 1 < NWV) ? edge[par][nb][0][wid + 1 < NWV ? wid + 1 : wid][cl] : 0.f;   // pixel 32
+      float outp[16];
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        const int j = p >> 2, e = p & 3;
+        float left, right;
+        if (e == 0) left = h ? rl[j] : (j > 0 ? rl[j > 0 ? j - 1 : 0] : eL); else left = d[nb][p - 1];
+        if (e == 3) right = h ? (j < 3 ? rf[j < 3 ? j + 1 : 3] : eR) : rf[j]; else right = d[nb][p + 1];
+        const float mid = d[nb][p];
+        // cross-correlation: input row r feeds out[r - 1] through taps row 2, out[r] through row 1, out[r + 1] through row 0
+        outp[p] = acc1[nb][p] + (tp[6] * left + tp[7] * mid + tp[8] * right);
+        acc1[nb][p] = acc2[nb][p] + (tp[3] * left + tp[4] * mid + tp[5] * right);
+        acc2[nb][p] = tp[0] * left + tp[1] * mid + tp[2] * right;
+      }
+#pragma unroll
+      for (int p = 0; p < 16; ++p) d[nb][p] = outp[p];       // d now holds the finished row r - 1 of this half
+    }
+    if (r >= 1 && live) {
+      float* __restrict__ dst = gout + (long)(r - 1) * W;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(d[0][4 * j + e]) * d[1][4 * j + e];
+        *reinterpret_cast<f32x4*>(dst + 8 * j) = v;            // pixels 32 wid + 8 j + 4 h .. + 3
+      }
+    }
+    if (r + 1 < H) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) cur[ks][pc] = nxt[ks][pc];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t pir_gdfn_fused_ws_bytes(int B, int C, int H, int W) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+  return (size_t)B * H * W * C * 6;
+}
+
+// g = gelu(dw3x3(W_in LN(x))[:hid]) * dw3x3(W_in LN(x))[hid:] with h0 never in memory.  w3: pir_split_bf16x3 pieces of W_in
+// [2 hid][C] (forward orientation, k padded to kp); ws: pir_gdfn_fused_ws_bytes bytes.  mean / rstd [B][HW]: optional outputs
+// (the statistics of the LayerNorm, for a backward pass).  1000 = shape not served (nothing launched).
+extern "C" int pir_gdfn_fused_fwd(const float* x, long x_bs, const float* ln_w, const float* ln_b, const void* w3, int kp,
+                                  const float* wd, float* g, long g_bs, void* ws, size_t ws_bytes, float* mean, float* rstd,
+                                  int B, int C, int hid, int H, int W, pir_stream_t stream) {
+  PIR_CHECK_ARG(x && ln_w && ln_b && w3 && wd && g && ws && B > 0 && C > 0 && hid > 0 && H > 0 && W > 0);
+  PIR_CHECK_ARG((mean == nullptr) == (rstd == nullptr));
+  if (!((C == 48 || C == 96) && (W == 128 || W == 64) && kp == C)) return 1000;
+  if ((reinterpret_cast<uintptr_t>(g) & 15) || g_bs % 4 || (reinterpret_cast<uintptr_t>(ws) & 15) || (reinterpret_cast<uintptr_t>(w3) & 15)) return 1000;
+  if (B > 65535 || (long)hid * H * W >= (1L << 31)) return 1000;
+  if (ws_bytes < pir_gdfn_fused_ws_bytes(B, C, H, W)) return PIR_ENOMEM;
+  hipStream_t s = (hipStream_t)stream;
+  bf16x8* xn3 = reinterpret_cast<bf16x8*>(ws);
+  const long pixels = (long)B * H * W;
+  const dim3 g1((unsigned)pir_cdiv(pixels, 256));
+  if (C == 96) hipLaunchKernelGGL((ln_split_rows_kernel<96>), g1, dim3(256), 0, s, x, x_bs, ln_w, ln_b, xn3, mean, rstd, H, W, B);
+  else hipLaunchKernelGGL((ln_split_rows_kernel<48>), g1, dim3(256), 0, s, x, x_bs, ln_w, ln_b, xn3, mean, rstd, H, W, B);
+  int st = pir_launch_status();
+  if (st) return st;
+  FusedArgs a;
+  a.xn3 = xn3; a.w3 = reinterpret_cast<const bf16x8*>(w3); a.wd = wd; a.g = g; a.g_bs = g_bs; a.hid = hid; a.H = H; a.W = W;
+  const dim3 grid((unsigned)pir_cdiv(hid, 32), (unsigned)B);
+  if (C == 96 && W == 128) hipLaunchKernelGGL((gdfn_fused_kernel<6, 4>), grid, dim3(256), 0, s, a);
+  else if (C == 96) hipLaunchKernelGGL((gdfn_fused_kernel<6, 2>), grid, dim3(128), 0, s, a);
+  else if (W == 128) hipLaunchKernelGGL((gdfn_fused_kernel<3, 4>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gdfn_fused_kernel<3, 2>), grid, dim3(128), 0, s, a);
+  return pir_launch_status();
+}

@@ -30,7 +30,7 @@ constexpr bool PIN_SCHED = PIR_PIN_SCHED;
 int g_nn_cfg = -1, g_nt_cfg = -1, g_nt_splits = 0, g_nn_x3 = -1, g_nt_x3 = -1;
 int g_nt_want_half = 5;   // knob 19: split-K workgroups per CU aimed at, in halves (bench sweep with two part-batch streams:
                           // 2: 100.5 ms, 4: 99.4, 5: 99.4, 6: 99.7-100.3, 8: 101.0, 12: 102.2; one stream: 6 beats 4 by 0.5 ms)
-int g_nt_group_wide = 1;   // knob 34: 128 x 192 tiles in the grouped low-resolution weight gradients (0: the single launches' tiles)
+int g_nt_group_wide = 0;   // knob 34: 128 x 192 tiles in the grouped low-resolution weight gradients (measured neutral in the two-stream step, round 4: off)
 int g_nt_tile96 = 0;  // knob 33: 96 x 96 three-wave tile for outputs of at most 96 x 96 (measured neutral in the step, round 4: off; 0 = the 128 x 96 tile)
 int g_nt_quad = -1;   // knob 14: gemm_nt_x3 four-lanes-per-row stage loads (-1 automatic, 0 never, 1 always)
 

@@ -873,6 +873,33 @@ def dwconv_gate_forward(x, w):
     return g
 
 
+GDFN_FUSED = _os.environ.get("PIR_GDFN_FUSED", "1") != "0"   # no_grad forward: project_in -> dw3x3 -> gate without h0 in memory
+
+
+def gdfn_fused_forward(x, ln_w, ln_b, win, wdw):
+    """g = gelu(dw3x3(W_in LN(x))[:hid]) * dw3x3(W_in LN(x))[hid:] (net/model.py:94-97 behind :195) with the 2 hid-channel
+    intermediate never written (pir_gdfn_fused_fwd); None where the kernel does not serve the shape."""
+    if not (USE_X3 and GDFN_FUSED) or ln_b is None:
+        return None
+    x = _planes(x)
+    b, c, h, w = x.shape
+    hid = win.shape[0] // 2
+    skey = ("gdfn_fused", _lib.KNOB_EPOCH[0], b, c, hid, h, w, _bs(x) % 4, x.data_ptr() % 16)
+    if _NOT_SERVED.get(skey) or c not in (48, 96) or w not in (64, 128):
+        return None
+    a3, kp = _split_weight(win, dgrad=False)
+    nbytes = int(lib.pir_gdfn_fused_ws_bytes(b, c, h, w))
+    ws = workspace((nbytes + 3) // 4, x.device, slot="gdfn_fused")
+    g = torch.empty((b, hid, h, w), dtype=torch.float32, device=x.device)
+    st = lib.pir_gdfn_fused_fwd(x.data_ptr(), _bs(x), ln_w.data_ptr(), ln_b.data_ptr(), a3.data_ptr(), kp, wdw.data_ptr(),
+                                g.data_ptr(), _bs(g), ws.data_ptr(), 4 * ws.numel(), None, None, b, c, hid, h, w, _stream())
+    if st == 1000:
+        _NOT_SERVED[skey] = True
+        return None
+    check(st, "pir_gdfn_fused_fwd")
+    return g
+
+
 def dwconv_gate_backward(x, w, dg):
     x, dg = _planes(x), _planes(dg)
     b, c2, h, wd = x.shape
@@ -1426,6 +1453,9 @@ class TransformerBlockFn(torch.autograd.Function):
                 gemm_nn(attn, (heads * c_ * c_, c_ * c_), c_, 1, qkv, 2 * c_all * hw_, (_bs(qkv), c_ * hw_), hw_,
                         out, 0, (c_all * hw_, c_ * hw_), hw_, c_, c_, hw_, b_, heads)
             x1 = conv1x1_forward(out, wproj, residual=x)
+        g = gdfn_fused_forward(x1, n2w, n2b, win, wdw2) if infer else None   # no_grad: h0 never exists
+        if g is not None:
+            return conv1x1_forward(g, wout, residual=x1, out=out_slot.tensor(x.shape) if out_slot is not None else None)
         h0 = ln_conv1x1_forward(x1, n2w, n2b, win) if infer else None
         xn2 = m2 = r2 = None
         if train_fold:

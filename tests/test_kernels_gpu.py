@@ -839,3 +839,30 @@ def test_grouped_weight_gradients_of_a_low_resolution_block(c, hw, b):
         assert torch.equal(outs[0][k], outs[1][k])
         single = ops.conv1x1_wgrad(items[k][0], items[k][1], items[k][2].new_empty(items[k][2].shape))
         close(outs[0][k], single.cpu(), rtol=2e-6)
+
+
+@pytest.mark.parametrize("b,c,h,w", [(2, 96, 24, 128), (1, 48, 9, 128), (2, 96, 16, 64), (3, 48, 5, 64), (1, 96, 1, 128), (1, 48, 2, 64)])
+def test_gdfn_forward_fused_without_the_hidden_tensor(b, c, h, w):
+    """pir_gdfn_fused_fwd: LayerNorm -> project_in -> depthwise 3x3 -> GELU gate (net/model.py:94-97 behind :195) with the
+    2 hid-channel tensor never in memory, against the reference arithmetic on the CPU and against the unfused HIP chain;
+    ragged last channel chunk (hid = 255 / 127), one- and two-row images, both row widths."""
+    from promptir_amd import ops
+
+    hid = int(c * 2.66)
+    x = rnd("x", b, c, h, w)
+    lw, lb = 1 + 0.1 * rnd("lw", c), 0.1 * rnd("lb", c)
+    win = rnd("win", 2 * hid, c, 1, 1) * (1.0 / c ** 0.5)
+    wdw = rnd("wdw", 2 * hid, 1, 3, 3) * 0.3
+    g = ops.gdfn_fused_forward(x.to(DEV), lw.to(DEV), lb.to(DEV), win.to(DEV), wdw.to(DEV))
+    assert g is not None, "shape not served"
+    mu = x.mean(1, keepdim=True)
+    xn = (x - mu) / torch.sqrt(x.var(1, keepdim=True, unbiased=False) + 1e-5) * lw.view(1, c, 1, 1) + lb.view(1, c, 1, 1)
+    t = F.conv2d(F.conv2d(xn, win), wdw, padding=1, groups=2 * hid)
+    ref = F.gelu(t[:, :hid]) * t[:, hid:]
+    close(g, ref, rtol=1e-5)
+    xn_d, _, _ = ops.layernorm_forward(x.to(DEV), lw.to(DEV), lb.to(DEV))
+    unfused = ops.dwconv_gate_forward(ops.conv1x1_forward(xn_d, win.to(DEV)), wdw.to(DEV))
+    close(g, unfused.cpu(), rtol=2e-6)
+    # shapes outside the served set fall back (None), nothing launched
+    assert ops.gdfn_fused_forward(rnd("y", 1, 96, 8, 32).to(DEV), lw.to(DEV), lb.to(DEV), win.to(DEV), wdw.to(DEV)) is None \\
+        if c == 96 else True
