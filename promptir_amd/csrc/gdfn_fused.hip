@@ -78,6 +78,7 @@ struct FusedArgs {
   const float* wd;            // depthwise weights [2 hid][9]
   float* g; long g_bs;        // [B][hid][H][W]
   int hid, H, W;
+  int band;                   // output rows per workgroup (blockIdx.z); each band re-multiplies one input row above and below
 };
 
 __device__ __forceinline__ float gelu_erf_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
@@ -121,7 +122,12 @@ void gdfn_fused_kernel(FusedArgs a) {
   const long row_units = (long)NWV * KS * 3 * 64;
   float* __restrict__ gout = a.g + (long)b * a.g_bs + (long)c1 * H * W + 32 * wid + 4 * h;
 
-  bf16x8 cur[KS][3], nxt[KS][3];
+  // ---- this workgroup's band of output rows [r0, r1); input rows r0 - 1 .. r1 (clipped to the image)
+  const int r0 = (int)blockIdx.z * a.band, r1 = r0 + a.band < H ? r0 + a.band : H;
+  const int rs = r0 > 0 ? r0 - 1 : 0;
+  const int rend = r1 == H ? H : r1;                         // last iteration: input row r1, or the flush (no input) at the image's end
+
+  bf16x8 cur[KS][3];
   auto load_row = [&](int r, bf16x8 (&f)[KS][3]) {
     const bf16x8* __restrict__ p = xbase + (long)r * row_units;
 #pragma unroll
@@ -129,7 +135,7 @@ void gdfn_fused_kernel(FusedArgs a) {
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc) f[ks][pc] = p[(ks * 3 + pc) * 64];
   };
-  load_row(0, cur);
+  load_row(rs, cur);
 
   // pending output rows: acc1 -> out[r - 1] once row r's bottom taps are in, acc2 -> out[r]
   float acc1[2][16], acc2[2][16];
@@ -138,9 +144,8 @@ void gdfn_fused_kernel(FusedArgs a) {
 #pragma unroll
     for (int p = 0; p < 16; ++p) { acc1[nb][p] = 0.f; acc2[nb][p] = 0.f; }
 
-  for (int r = 0; r <= H; ++r) {
+  for (int r = rs; r <= rend; ++r) {
     const bool have = r < H;                                 // row H is the flush iteration: no input, out[H - 1] leaves
-    if (r + 1 < H) load_row(r + 1, nxt);
     f32x16 d[2];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
@@ -157,6 +162,8 @@ void gdfn_fused_kernel(FusedArgs a) {
           d[nb] = pir_mfma_x3(cur[ks][0], cur[ks][1], cur[ks][2], bh, bm, bl, d[nb]);      // D[pixel][channel]
         }
     }
+    // the fragments are consumed: the next row's fly into the same registers during the filter / gate phase below
+    if (r + 1 <= rend && r + 1 < H) load_row(r + 1, cur);
     // ---- block-edge pixels of the new row for the neighbouring waves (pixel 0: lane half 0, register 0; pixel 31: half 1, register 15)
     const int par = r & 1;
 #pragma unroll
@@ -191,7 +198,7 @@ void gdfn_fused_kernel(FusedArgs a) {
 #pragma unroll
       for (int p = 0; p < 16; ++p) d[nb][p] = outp[p];       // d now holds the finished row r - 1 of this half
     }
-    if (r >= 1 && live) {
+    if (r - 1 >= r0 && r - 1 < r1 && live) {
       float* __restrict__ dst = gout + (long)(r - 1) * W;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -200,12 +207,6 @@ void gdfn_fused_kernel(FusedArgs a) {
         for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(d[0][4 * j + e]) * d[1][4 * j + e];
         *reinterpret_cast<f32x4*>(dst + 8 * j) = v;            // pixels 32 wid + 8 j + 4 h .. + 3
       }
-    }
-    if (r + 1 < H) {
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) cur[ks][pc] = nxt[ks][pc];
     }
   }
 }
@@ -239,7 +240,14 @@ extern "C" int pir_gdfn_fused_fwd(const float* x, long x_bs, const float* ln_w, 
   if (st) return st;
   FusedArgs a;
   a.xn3 = xn3; a.w3 = reinterpret_cast<const bf16x8*>(w3); a.wd = wd; a.g = g; a.g_bs = g_bs; a.hid = hid; a.H = H; a.W = W;
-  const dim3 grid((unsigned)pir_cdiv(hid, 32), (unsigned)B);
+  // bands of output rows: enough workgroups for two per CU (a workgroup is one wave per SIMD); each band re-multiplies
+  // two halo rows, so no band is shorter than 16 rows (12 % recompute)
+  const long base = pir_cdiv(hid, 32) * (long)B;
+  long nbands = pir_cdiv(2L * PIR_NUM_CU, base);
+  if (nbands > H / 16) nbands = H / 16;
+  if (nbands < 1) nbands = 1;
+  a.band = (int)pir_cdiv(H, nbands);
+  const dim3 grid((unsigned)pir_cdiv(hid, 32), (unsigned)B, (unsigned)pir_cdiv(H, a.band));
   if (C == 96 && W == 128) hipLaunchKernelGGL((gdfn_fused_kernel<6, 4>), grid, dim3(256), 0, s, a);
   else if (C == 96) hipLaunchKernelGGL((gdfn_fused_kernel<6, 2>), grid, dim3(128), 0, s, a);
   else if (W == 128) hipLaunchKernelGGL((gdfn_fused_kernel<3, 4>), grid, dim3(256), 0, s, a);
