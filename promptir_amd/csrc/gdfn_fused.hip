@@ -81,11 +81,26 @@ struct FusedArgs {
   int band;                   // output rows per workgroup (blockIdx.z); each band re-multiplies one input row above and below
 };
 
-__device__ __forceinline__ float gelu_erf_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+// FAST = false: libm erff, the arithmetic of the unfused forward (pir_dwconv3x3_gate); FAST = true: Abramowitz & Stegun
+// 7.1.26 (|error| <= 1.5e-7, what the backward kernels use; checked against fp64 in tests) - a third of the instructions
+template <bool FAST>
+__device__ __forceinline__ float gelu_erf_f(float v) {
+  if (!FAST) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+  const float ax = fabsf(v) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  const float e = __expf(-ax * ax);
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float erf_abs = fmaf(-p * t, e, 1.f);
+  return v * fmaf(0.5f, copysignf(erf_abs, v), 0.5f);
+}
 
-// NWV = W / 32 waves per workgroup, KS = C / 16
-template <int KS, int NWV>
-__global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(1)))
+// NWV = W / 32 waves per workgroup, KS = C / 16; two waves per SIMD (one workgroup's MFMAs run under another's filter /
+// gate arithmetic: a row costs 72 MFMAs and ~1200 vector instructions, serial inside one wave)
+template <int KS, int NWV, bool FAST>
+__global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(2)))
 void gdfn_fused_kernel(FusedArgs a) {
   constexpr int T = NWV * 64;
   constexpr int PUNITS = 3 * KS * 2 * 64;                 // weight panel: [piece][ks][h][64 rows]
@@ -204,14 +219,21 @@ void gdfn_fused_kernel(FusedArgs a) {
       for (int j = 0; j < 4; ++j) {
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(d[0][4 * j + e]) * d[1][4 * j + e];
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f<FAST>(d[0][4 * j + e]) * d[1][4 * j + e];
         *reinterpret_cast<f32x4*>(dst + 8 * j) = v;            // pixels 32 wid + 8 j + 4 h .. + 3
       }
     }
   }
 }
 
+int g_fused_fast_erf = 0;   // knob 35: 1 = the backward kernels' erf approximation in the fused forward gate (default: libm erff)
+
 }  // namespace
+
+int pir_gdfn_fused_tune(int knob, int value) {
+  if (knob == 35) { g_fused_fast_erf = value; return PIR_OK; }
+  return PIR_EINVAL;
+}
 
 extern "C" size_t pir_gdfn_fused_ws_bytes(int B, int C, int H, int W) {
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
@@ -243,14 +265,17 @@ extern "C" int pir_gdfn_fused_fwd(const float* x, long x_bs, const float* ln_w, 
   // bands of output rows: enough workgroups for two per CU (a workgroup is one wave per SIMD); each band re-multiplies
   // two halo rows, so no band is shorter than 16 rows (12 % recompute)
   const long base = pir_cdiv(hid, 32) * (long)B;
-  long nbands = pir_cdiv(2L * PIR_NUM_CU, base);
+  long nbands = pir_cdiv(4L * PIR_NUM_CU, base);
   if (nbands > H / 16) nbands = H / 16;
   if (nbands < 1) nbands = 1;
   a.band = (int)pir_cdiv(H, nbands);
   const dim3 grid((unsigned)pir_cdiv(hid, 32), (unsigned)B, (unsigned)pir_cdiv(H, a.band));
-  if (C == 96 && W == 128) hipLaunchKernelGGL((gdfn_fused_kernel<6, 4>), grid, dim3(256), 0, s, a);
-  else if (C == 96) hipLaunchKernelGGL((gdfn_fused_kernel<6, 2>), grid, dim3(128), 0, s, a);
-  else if (W == 128) hipLaunchKernelGGL((gdfn_fused_kernel<3, 4>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((gdfn_fused_kernel<3, 2>), grid, dim3(128), 0, s, a);
+#define PIR_GF(KS_, NW_) do { if (g_fused_fast_erf) hipLaunchKernelGGL((gdfn_fused_kernel<KS_, NW_, true>), grid, dim3(NW_ * 64), 0, s, a); \
+                             else hipLaunchKernelGGL((gdfn_fused_kernel<KS_, NW_, false>), grid, dim3(NW_ * 64), 0, s, a); } while (0)
+  if (C == 96 && W == 128) PIR_GF(6, 4);
+  else if (C == 96) PIR_GF(6, 2);
+  else if (W == 128) PIR_GF(3, 4);
+  else PIR_GF(3, 2);
+#undef PIR_GF
   return pir_launch_status();
 }
