@@ -873,7 +873,10 @@ def dwconv_gate_forward(x, w):
     return g
 
 
-GDFN_FUSED = _os.environ.get("PIR_GDFN_FUSED", "1") != "0"   # no_grad forward: project_in -> dw3x3 -> gate without h0 in memory
+# no_grad forward: project_in -> dw3x3 -> gate without h0 in memory (pir_gdfn_fused_fwd).  OFF by default: the kernel moves
+# 31 % fewer bytes per block but its filter / gate arithmetic (~1230 vector instructions per image row and wave beside 72
+# MFMAs) makes it no faster than the pair it replaces at 96 channels and slower at batch 8 (profiles/r04_gdfn_fused_ab.txt)
+GDFN_FUSED = _os.environ.get("PIR_GDFN_FUSED", "0") != "0"
 
 
 def gdfn_fused_forward(x, ln_w, ln_b, win, wdw):

@@ -842,12 +842,13 @@ def test_grouped_weight_gradients_of_a_low_resolution_block(c, hw, b):
 
 
 @pytest.mark.parametrize("b,c,h,w", [(2, 96, 24, 128), (1, 48, 9, 128), (2, 96, 16, 64), (3, 48, 5, 64), (1, 96, 1, 128), (1, 48, 2, 64)])
-def test_gdfn_forward_fused_without_the_hidden_tensor(b, c, h, w):
+def test_gdfn_forward_fused_without_the_hidden_tensor(b, c, h, w, monkeypatch):
     """pir_gdfn_fused_fwd: LayerNorm -> project_in -> depthwise 3x3 -> GELU gate (net/model.py:94-97 behind :195) with the
     2 hid-channel tensor never in memory, against the reference arithmetic on the CPU and against the unfused HIP chain;
     ragged last channel chunk (hid = 255 / 127), one- and two-row images, both row widths."""
     from promptir_amd import ops
 
+    monkeypatch.setattr(ops, "GDFN_FUSED", True)      # opt-in kernel (PIR_GDFN_FUSED=1)
     hid = int(c * 2.66)
     x = rnd("x", b, c, h, w)
     lw, lb = 1 + 0.1 * rnd("lw", c), 0.1 * rnd("lb", c)

@@ -8,6 +8,8 @@ import torch
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from promptir_amd import ops  # noqa: E402
 
+ops.GDFN_FUSED = True
+
 dev = torch.device("cuda", 0)
 
 
