@@ -72,7 +72,10 @@ extern "C" int pir_tiles_gather(const float* img, long img_bs, float* out, int B
                                 pir_stream_t stream) {
   PIR_CHECK_ARG(img && out && B > 0 && C > 0 && H > 0 && W > 0 && Hp >= H && Wp >= W);
   PIR_CHECK_ARG(tile_h > 0 && tile_w > 0 && tile_h <= Hp && tile_w <= Wp && stride_h > 0 && stride_w > 0 && nth > 0 && ntw > 0);
-  PIR_CHECK_ARG(Hp - H < H && Wp - W < W && (pad_mode == 0 || pad_mode == 1));
+  PIR_CHECK_ARG(pad_mode == 0 || pad_mode == 1);
+  // reflect (H + k -> H - 2 - k) reaches row 0 at k = H - 2; the flipped copy of test.py:102-103 (H + k -> H - 1 - k) at k = H - 1:
+  // an image of exactly 64 rows is extended to 128 by its whole mirror image
+  PIR_CHECK_ARG(Hp - H <= H - 1 + pad_mode && Wp - W <= W - 1 + pad_mode);
   const long total = (long)B * nth * ntw * C * tile_h * tile_w;
   hipLaunchKernelGGL(tiles_gather_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img, img_bs, out,
                      B, C, H, W, Hp, Wp, tile_h, tile_w, stride_h, stride_w, nth, ntw, pad_mode);

@@ -104,3 +104,17 @@ def test_config4_full_size_full_depth_vs_reference_golden():
             cnt[..., i:i + 128, j:j + 128] += 1.0
             k += 1
     assert torch.equal(y, (acc / cnt).clamp(0.0, 1.0))
+
+
+def test_mirror_pad_of_an_image_that_is_exactly_one_block_high():
+    """test.py:100-104 on a 64 x 80 image: (H // 64 + 1) * 64 = 128 rows, i.e. the whole flipped image is appended (the
+    derain / dehaze evaluation of a 64-row crop hit a too-strict argument check here in round 4)."""
+    import torch
+
+    from promptir_amd.tile import mirror_pad_64
+
+    x = torch.rand(1, 3, 64, 80, device="cuda:0")
+    p, h, w = mirror_pad_64(x)
+    ref = torch.cat([x, torch.flip(x, [2])], 2)[:, :, :128, :]
+    ref = torch.cat([ref, torch.flip(ref, [3])], 3)[:, :, :, :128]
+    assert (h, w) == (64, 80) and torch.equal(p, ref)
