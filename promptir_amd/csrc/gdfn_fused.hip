@@ -26,6 +26,7 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------------------------
 // pass 1: LayerNorm + bf16x3 split into fragment order.  One thread per pixel; the C channel values live in registers.
@@ -142,24 +143,33 @@ void gdfn_fused_kernel(FusedArgs a) {
   const int rs = r0 > 0 ? r0 - 1 : 0;
   const int rend = r1 == H ? H : r1;                         // last iteration: input row r1, or the flush (no input) at the image's end
 
+  // A row's fragments arrive in two halves: k-steps [0, KSL) are fetched a whole filter / gate phase ahead, k-steps
+  // [KSL, KS) at the start of the row's own MFMA phase (their latency hides under the first half's MFMAs) - they are
+  // not live during the filter phase, where the register pressure peaks.
+  constexpr int KSL = KS / 2;
   bf16x8 cur[KS][3];
-  auto load_row = [&](int r, bf16x8 (&f)[KS][3]) {
+  auto load_part = [&](int r, int k0, int k1) {
     const bf16x8* __restrict__ p = xbase + (long)r * row_units;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
+      if (ks >= k0 && ks < k1) {
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) f[ks][pc] = p[(ks * 3 + pc) * 64];
+        for (int pc = 0; pc < 3; ++pc) cur[ks][pc] = p[(ks * 3 + pc) * 64];
+      }
   };
-  load_row(rs, cur);
+  load_part(rs, 0, KSL);
 
-  // pending output rows: acc1 -> out[r - 1] once row r's bottom taps are in, acc2 -> out[r]
-  float acc1[2][16], acc2[2][16];
+  // Pending output rows in registers.  Input row r adds its three horizontally filtered contributions: taps row 2 completes
+  // out[r - 1] (held in P), taps row 1 goes into out[r] (held in Q), taps row 0 STARTS out[r + 1] - written into P's
+  // registers once the finished row has left them.  P and Q swap roles every row (the loop is unrolled by two): no moves.
+  float accA[2][16], accB[2][16];
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-    for (int p = 0; p < 16; ++p) { acc1[nb][p] = 0.f; acc2[nb][p] = 0.f; }
+    for (int p = 0; p < 16; ++p) { accA[nb][p] = 0.f; accB[nb][p] = 0.f; }
+  const bool hb = h != 0;
 
-  for (int r = rs; r <= rend; ++r) {
+  auto row_step = [&](int r, float (&P)[2][16], float (&Q)[2][16]) {
     const bool have = r < H;                                 // row H is the flush iteration: no input, out[H - 1] leaves
     f32x16 d[2];
 #pragma unroll
@@ -167,63 +177,98 @@ void gdfn_fused_kernel(FusedArgs a) {
 #pragma unroll
       for (int p = 0; p < 16; ++p) d[nb][p] = 0.f;
     if (have) {
+      load_part(r, KSL, KS);
       const bf16x8* wp = panel + h * 64 + cl + (r >> 30);    // opaque zero: keeps the panel reads inside the loop
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 bw[2][3];
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-          const bf16x8 bh = wp[((0 * KS + ks) * 2) * 64 + nb * 32], bm = wp[((1 * KS + ks) * 2) * 64 + nb * 32],
-                       bl = wp[((2 * KS + ks) * 2) * 64 + nb * 32];
-          d[nb] = pir_mfma_x3(cur[ks][0], cur[ks][1], cur[ks][2], bh, bm, bl, d[nb]);      // D[pixel][channel]
-        }
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) bw[nb][pc] = wp[((pc * KS + ks) * 2) * 64 + nb * 32];
+        // the two halves' chains interleaved term by term (same per-accumulator term order as pir_mfma_x3)
+#define PIR_GF_TERM(A_, B_) _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) \
+        d[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[ks][A_], bw[nb][B_], d[nb], 0, 0, 0);
+        PIR_GF_TERM(2, 0) PIR_GF_TERM(0, 2) PIR_GF_TERM(1, 1) PIR_GF_TERM(1, 0) PIR_GF_TERM(0, 1) PIR_GF_TERM(0, 0)
+#undef PIR_GF_TERM
+      }
     }
-    // the fragments are consumed: the next row's fly into the same registers during the filter / gate phase below
-    if (r + 1 <= rend && r + 1 < H) load_row(r + 1, cur);
+    // the fragments are consumed: the first half of the next row's flies during the filter / gate phase below
+    if (r + 1 <= rend && r + 1 < H) load_part(r + 1, 0, KSL);
     // ---- block-edge pixels of the new row for the neighbouring waves (pixel 0: lane half 0, register 0; pixel 31: half 1, register 15)
     const int par = r & 1;
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) edge[par][nb][h][wid][cl] = h == 0 ? d[nb][0] : d[nb][15];
+    for (int nb = 0; nb < 2; ++nb) edge[par][nb][h][wid][cl] = hb ? d[nb][15] : d[nb][0];
     __syncthreads();
+    // ---- horizontal neighbours of the run ends: partner lane half, block ends from the neighbouring waves (zero at the border)
+    float lft[2][4], rgt[2][4];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-      const float (&tp)[9] = nb == 0 ? t1 : t2;
-      // run ends from the partner lane half
       float rf[4], rl[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         rf[j] = __shfl_xor(d[nb][4 * j], 32, 64);
         rl[j] = __shfl_xor(d[nb][4 * j + 3], 32, 64);
       }
-      // block ends from the neighbouring waves (zero padding at the image border)
-      const float eL = (h == 0 && wid > 0) ? edge[par][nb][1][wid > 0 ? wid - 1 : 0][cl] : 0.f;          // pixel -1
-      const float eR = (h == 1 && wid + 1 < NWV) ? edge[par][nb][0][wid + 1 < NWV ? wid + 1 : wid][cl] : 0.f;   // pixel 32
-      float outp[16];
-#pragma unroll
-      for (int p = 0; p < 16; ++p) {
-        const int j = p >> 2, e = p & 3;
-        float left, right;
-        if (e == 0) left = h ? rl[j] : (j > 0 ? rl[j > 0 ? j - 1 : 0] : eL); else left = d[nb][p - 1];
-        if (e == 3) right = h ? (j < 3 ? rf[j < 3 ? j + 1 : 3] : eR) : rf[j]; else right = d[nb][p + 1];
-        const float mid = d[nb][p];
-        // cross-correlation: input row r feeds out[r - 1] through taps row 2, out[r] through row 1, out[r + 1] through row 0
-        outp[p] = acc1[nb][p] + (tp[6] * left + tp[7] * mid + tp[8] * right);
-        acc1[nb][p] = acc2[nb][p] + (tp[3] * left + tp[4] * mid + tp[5] * right);
-        acc2[nb][p] = tp[0] * left + tp[1] * mid + tp[2] * right;
-      }
-#pragma unroll
-      for (int p = 0; p < 16; ++p) d[nb][p] = outp[p];       // d now holds the finished row r - 1 of this half
-    }
-    if (r - 1 >= r0 && r - 1 < r1 && live) {
-      float* __restrict__ dst = gout + (long)(r - 1) * W;
+      const float eL = wid > 0 ? edge[par][nb][1][wid > 0 ? wid - 1 : 0][cl] : 0.f;                 // pixel -1 (lane half 0 uses it)
+      const float eR = wid + 1 < NWV ? edge[par][nb][0][wid + 1 < NWV ? wid + 1 : wid][cl] : 0.f;    // pixel 32 (lane half 1)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f<FAST>(d[0][4 * j + e]) * d[1][4 * j + e];
-        *reinterpret_cast<f32x4*>(dst + 8 * j) = v;            // pixels 32 wid + 8 j + 4 h .. + 3
+        lft[nb][j] = hb ? rl[j] : (j > 0 ? rl[j > 0 ? j - 1 : 0] : eL);
+        rgt[nb][j] = hb ? (j < 3 ? rf[j < 3 ? j + 1 : 3] : eR) : rf[j];
       }
     }
+    const bool store = r - 1 >= r0 && r - 1 < r1 && live;
+    float* __restrict__ dst = gout + (long)(r - 1) * W;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // the four pixels of run j as two pairs; cross-correlation: input row r feeds out[r - 1] through taps row 2, out[r]
+      // through row 1, out[r + 1] through row 0
+      f32x2 l2[2][2], m2[2][2], r2[2][2];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const float a0 = d[nb][4 * j], a1 = d[nb][4 * j + 1], a2 = d[nb][4 * j + 2], a3 = d[nb][4 * j + 3];
+        l2[nb][0] = f32x2{lft[nb][j], a0}; m2[nb][0] = f32x2{a0, a1}; r2[nb][0] = f32x2{a1, a2};
+        l2[nb][1] = f32x2{a1, a2};         m2[nb][1] = f32x2{a2, a3}; r2[nb][1] = f32x2{a3, rgt[nb][j]};
+      }
+      f32x2 fin[2][2];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const float (&tp)[9] = nb == 0 ? t1 : t2;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int p = 4 * j + 2 * k;
+          f32x2 o = f32x2{P[nb][p], P[nb][p + 1]};
+          o = __builtin_elementwise_fma(f32x2{tp[6], tp[6]}, l2[nb][k], o);
+          o = __builtin_elementwise_fma(f32x2{tp[7], tp[7]}, m2[nb][k], o);
+          o = __builtin_elementwise_fma(f32x2{tp[8], tp[8]}, r2[nb][k], o);
+          fin[nb][k] = o;
+          f32x2 q2 = f32x2{Q[nb][p], Q[nb][p + 1]};
+          q2 = __builtin_elementwise_fma(f32x2{tp[3], tp[3]}, l2[nb][k], q2);
+          q2 = __builtin_elementwise_fma(f32x2{tp[4], tp[4]}, m2[nb][k], q2);
+          q2 = __builtin_elementwise_fma(f32x2{tp[5], tp[5]}, r2[nb][k], q2);
+          Q[nb][p] = q2[0]; Q[nb][p + 1] = q2[1];
+          f32x2 n2 = f32x2{tp[0], tp[0]} * l2[nb][k];
+          n2 = __builtin_elementwise_fma(f32x2{tp[1], tp[1]}, m2[nb][k], n2);
+          n2 = __builtin_elementwise_fma(f32x2{tp[2], tp[2]}, r2[nb][k], n2);
+          P[nb][p] = n2[0]; P[nb][p + 1] = n2[1];          // out[r + 1] starts in the registers out[r - 1] just left
+        }
+      }
+      if (store) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f<FAST>(fin[0][e >> 1][e & 1]) * fin[1][e >> 1][e & 1];
+        *reinterpret_cast<f32x4*>(dst + 8 * j) = v;          // pixels 32 wid + 8 j + 4 h .. + 3
+      }
+    }
+  };
+
+  int r = rs;
+  for (; r + 1 <= rend; r += 2) {
+    row_step(r, accA, accB);
+    row_step(r + 1, accB, accA);
   }
+  if (r <= rend) row_step(r, accA, accB);
 }
 
 int g_fused_fast_erf = 0;   // knob 35: 1 = the backward kernels' erf approximation in the fused forward gate (default: libm erff)
