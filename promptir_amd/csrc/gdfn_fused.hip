@@ -79,7 +79,8 @@ struct FusedArgs {
   const float* wd;            // depthwise weights [2 hid][9]
   float* g; long g_bs;        // [B][hid][H][W]
   int hid, H, W;
-  int band;                   // output rows per workgroup (blockIdx.z); each band re-multiplies one input row above and below
+  int band;                   // output rows per workgroup; each band re-multiplies one input row above and below
+  int nchunks, nbands, B;     // ceil(hid / 32), bands per image, images
 };
 
 // FAST = false: libm erff, the arithmetic of the unfused forward (pir_dwconv3x3_gate); FAST = true: Abramowitz & Stegun
@@ -109,7 +110,15 @@ void gdfn_fused_kernel(FusedArgs a) {
   __shared__ float edge[2][2][2][NWV][32];                // [row parity][half nb][side: 0 = first pixel, 1 = last pixel][wave][channel]
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, cl = lane & 31;
-  const int q = blockIdx.x, b = blockIdx.y;
+  // XCD-aware order (workgroups are dealt round-robin over the 8 XCDs, each with its own 4 MB L2): the nchunks
+  // workgroups that read the SAME fragments - one (image, band) unit - get linear ids of equal residue mod 8 and
+  // consecutive rank inside it, so the unit's 1.3 MB of fragments come from HBM once per XCD and from that L2 otherwise.
+  // (In (chunk, image, band) grid order the chunks of a unit landed on eight different XCDs and every one of them
+  // streamed the whole tensor: the first versions of this kernel were bound by exactly that.)
+  const int lin = (int)blockIdx.x, xcd = lin & 7, t = lin >> 3;
+  const int q = t % a.nchunks, unit = (t / a.nchunks) * 8 + xcd;
+  if (unit >= a.B * a.nbands) return;
+  const int b = unit / a.nbands, band_i = unit - b * a.nbands;
   const int hid = a.hid, H = a.H, W = a.W, M = 2 * hid;
   const int npairs = hid - 32 * q < 32 ? hid - 32 * q : 32;
 
@@ -139,7 +148,7 @@ void gdfn_fused_kernel(FusedArgs a) {
   float* __restrict__ gout = a.g + (long)b * a.g_bs + (long)c1 * H * W + 32 * wid + 4 * h;
 
   // ---- this workgroup's band of output rows [r0, r1); input rows r0 - 1 .. r1 (clipped to the image)
-  const int r0 = (int)blockIdx.z * a.band, r1 = r0 + a.band < H ? r0 + a.band : H;
+  const int r0 = band_i * a.band, r1 = r0 + a.band < H ? r0 + a.band : H;
   const int rs = r0 > 0 ? r0 - 1 : 0;
   const int rend = r1 == H ? H : r1;                         // last iteration: input row r1, or the flush (no input) at the image's end
 
@@ -314,7 +323,9 @@ extern "C" int pir_gdfn_fused_fwd(const float* x, long x_bs, const float* ln_w, 
   if (nbands > H / 16) nbands = H / 16;
   if (nbands < 1) nbands = 1;
   a.band = (int)pir_cdiv(H, nbands);
-  const dim3 grid((unsigned)pir_cdiv(hid, 32), (unsigned)B, (unsigned)pir_cdiv(H, a.band));
+  a.nchunks = (int)pir_cdiv(hid, 32); a.nbands = (int)pir_cdiv(H, a.band); a.B = B;
+  const long units = (long)B * a.nbands;
+  const dim3 grid((unsigned)(pir_cdiv(units, 8) * 8 * a.nchunks));
 #define PIR_GF(KS_, NW_) do { if (g_fused_fast_erf) hipLaunchKernelGGL((gdfn_fused_kernel<KS_, NW_, true>), grid, dim3(NW_ * 64), 0, s, a); \
                              else hipLaunchKernelGGL((gdfn_fused_kernel<KS_, NW_, false>), grid, dim3(NW_ * 64), 0, s, a); } while (0)
   if (C == 96 && W == 128) PIR_GF(6, 4);
