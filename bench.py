@@ -439,7 +439,7 @@ def main():
                                    f"batch {args.batch}/GPU x 3x{args.patch}x{args.patch}, all-in-one sigma mix "
                                    f"({baseline_cfg})",
                        "global_batch": args.batch * world, "patch": args.patch, "parallelism": f"dp{world}",
-                       "execution": f"hipGraph={int(trainer.graph)}, part-batch streams={trainer.micro_streams}" +
+                       "execution": f"hipGraph={int(trainer.graph)}, part-batch streams={trainer._nparts(args.batch)}" +
                                     (", backward in 3 segments with overlapped gradient all-reduce" if trainer.staged else ""),
                        "process_group": dist.get_backend() if dist.is_initialized() else None,
                        "world": world, "device_index": local, "replica_param_spread": spread,
