@@ -241,7 +241,9 @@ class DataParallelTrainer:
             graph = os.environ.get("PIR_GRAPH", "1") != "0"
         self.graph, self._graph, self._graph_shape = bool(graph) and self.opt.param.is_cuda, None, None
         if micro_streams is None:   # part streams only pay inside the graph (eagerly the extra launches bind the CPU)
-            micro_streams = int(os.environ.get("PIR_MICRO_STREAMS", "4" if self.graph else "1"))
+            # (PIR_MICRO_STREAMS=4: four parts of eight at batch 32 measured -0.5 ... -0.9 ms per step, round 4, for twice the
+            # launches - 6211 instead of 3131 per step - and two more flat gradient buffers; the default stays at two)
+            micro_streams = int(os.environ.get("PIR_MICRO_STREAMS", "2" if self.graph else "1"))
         self.micro_streams = max(1, micro_streams) if self.opt.param.is_cuda else 1
         self.min_part = max(0, int(os.environ.get("PIR_MIN_PART", "0")))     # 0: the rule of _nparts
         self._split_sig = None
@@ -358,9 +360,9 @@ class DataParallelTrainer:
         return self.opt.stages is not None and len(self.opt.stages) == 3 and hasattr(self.net, "encode_levels")
 
     def _nparts(self, b: int) -> int:
-        """Part-batch streams for a batch of b: parts of eight samples, but two parts from eight samples on (measured in the
-        graph, round 4, same box: batch 32 in 2 / 3 / 4 parts 92.6 / 92.6 / 91.7 ms; batch 8 in 2 x 4 35.6 ms, 4 x 2 37.1 ms, one
-        part 36.9 ms).  PIR_MIN_PART overrides the part size."""
+        """Part-batch streams for a batch of b (at most `micro_streams`): parts of eight samples, but two parts from eight
+        samples on (measured in the graph, round 4, same box: batch 32 in 2 / 3 / 4 parts 92.6 / 92.6 / 91.7 ms; batch 8 in
+        2 x 4 35.6 ms, 4 x 2 37.1 ms, one part 36.9 ms).  PIR_MIN_PART overrides the part size."""
         if self.min_part:
             return min(self.micro_streams, max(1, b // self.min_part))
         return min(self.micro_streams, max(b // 8, 2 if b >= 8 else 1))
