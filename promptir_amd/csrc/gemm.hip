@@ -954,6 +954,7 @@ int pir_gdfn_wave_tune(int knob, int value);   // gdfn_bwd.hip
 int pir_stencil_wave_tune(int knob, int value);   // stencil_wave.hip
 int pir_ln_tune(int knob, int value);             // norm.hip
 int pir_gdfn_fused_tune(int knob, int value);     // gdfn_fused.hip
+int pir_mdta_dqk_tune(int knob, int value);       // mdta_dqk.hip
 
 extern "C" int pir_tune_set(int knob, int value) {
   switch (knob) {
@@ -970,6 +971,7 @@ extern "C" int pir_tune_set(int knob, int value) {
     case 33: g_nt_tile96 = value; return PIR_OK;
     case 34: g_nt_group_wide = value; return PIR_OK;
     case 35: return pir_gdfn_fused_tune(knob, value);
+    case 36: return pir_mdta_dqk_tune(knob, value);
     case 19: g_nt_want_half = value; return PIR_OK;
     case 20: return pir_nn_res_tune(knob, value);
     case 21: case 22: case 23: case 24: return pir_nn_res_tune2(knob, value);

@@ -12,8 +12,9 @@
 // with q against dG^T for dk.  Row r of the raw load (k-step ks, instruction t) is 16 ks + 8 t + 4 h + j: that is the row
 // 32 i + 8 G + 4 h + j an accumulator holds after its transpose, with (i, G) = (ks / 2, 2 (ks % 2) + t); the MFMA's k
 // index within a 16-deep step is permuted accordingly (lane half h holds k = 4h .. 4h+3 and 8 + 4h .. 8 + 4h + 3), and the
-// dG panels in LDS are written with the same permutation.  c = 48 only (every level of the network except the three noise
-// blocks, which keep the two-GEMM path).
+// dG panels in LDS are written with the same permutation.  c = 48 (every level of the network except the noise blocks) and,
+// round 4, c = 96 (the one-head blocks of decoder level 1 and the refinement stage, the 128^2 level: four waves per
+// workgroup, one per SIMD with the whole register file - 110 KB of dG panels per workgroup); the noise blocks keep the two GEMMs.
 #include "gemm_common.h"
 #include "wide_tiles.h"
 
@@ -48,11 +49,13 @@ struct DqkArgs {
   int per_wg;            // 32-pixel blocks per workgroup (a multiple of 8)
 };
 
-constexpr int C48 = 48, KS = 3, PR = 64;            // rows per head, k-steps, padded panel rows
-constexpr int PANEL = 3 * 2 * KS * PR;              // 16-byte units of one split dG panel
-
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
+// C48: rows per head (48 or 96), KS = C48 / 16 k-steps, PR: padded panel rows (a multiple of 32), NW: waves per workgroup,
+// PF: prefetch the next block's planes under this block's MFMAs (needs 2 x KS x 8 more registers)
+template <int C48, int KS, int PR, int NW, bool PF>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 2 : 1)))
 void mdta_dqk_kernel(DqkArgs p) {
+  constexpr int PANEL = 3 * 2 * KS * PR;              // 16-byte units of one split dG panel
+  constexpr int NG = C48 / 8, NTI = PR / 32;          // 8-row groups a lane stores, 32-row output tiles
   __shared__ bf16x8 smem[2 * PANEL];                // dG (rows i, k = j) and dG^T (rows j, k = i)
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, r = lane & 31;
@@ -63,7 +66,7 @@ void mdta_dqk_kernel(DqkArgs p) {
   // ---- prologue: both orientations of dG as bf16x3 panels.  Unit (kgi = 2 ks + h', row) holds the eight k values
   // 16 ks + 4 h' + (0..3) and 16 ks + 8 + 4 h' + (0..3) - the permutation the activation fragments use.
   const float* __restrict__ dG = p.dgram + (long)bh * C48 * C48;
-  for (int u = tid; u < 2 * 2 * KS * PR; u += 512) {
+  for (int u = tid; u < 2 * 2 * KS * PR; u += NW * 64) {
     const int pan = u / (2 * KS * PR), rest = u - pan * (2 * KS * PR);
     const int kgi = rest / PR, row = rest - kgi * PR;
     const int ks = kgi >> 1, hh = kgi & 1;
@@ -91,9 +94,9 @@ void mdta_dqk_kernel(DqkArgs p) {
   const __amdgpu_buffer_rsrc_t dqrs = pir_make_rsrc(dqb, bytes), dkrs = pir_make_rsrc(dqb + p.dk_off, bytes);
   const int lrow = (4 * h + qj) * HW * 4;            // lane's row offset inside a group of 8 rows, bytes
   // row scales of the rows this lane stores: row(i, G) = 32 i + 8 G + 4 h + qj for the six groups below 48
-  float aq[6], ak[6];
+  float aq[NG], ak[NG];
 #pragma unroll
-  for (int e = 0; e < 6; ++e) {
+  for (int e = 0; e < NG; ++e) {
     const int row = 8 * e + 4 * h + qj;
     aq[e] = p.alpha_q[(long)b * p.heads * C48 + hd * C48 + row];
     ak[e] = p.alpha_k[(long)b * p.heads * C48 + hd * C48 + row];
@@ -122,28 +125,28 @@ void mdta_dqk_kernel(DqkArgs p) {
     }
   };
   // out = panel x fragments + scale * raw, rows < 48: tile i = 0 (groups 0..3), i = 1 (groups 4, 5)
-  auto product = [&](int pan, const DFrag3 (&f)[KS], const f32x4 (&raw)[KS][2], const float (&al)[6],
+  auto product = [&](int pan, const DFrag3 (&f)[KS], const f32x4 (&raw)[KS][2], const float (&al)[NG],
                      const __amdgpu_buffer_rsrc_t& ors, int bk) {
     const bf16x8* ap = smem + pan * PANEL + h * PR + r + (bk >> 30);   // opaque zero: keeps the reads inside the loop
-    f32x16 acc[2];
+    f32x16 acc[NTI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NTI; ++i)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      bf16x8 ah[2], am[2], al2[2];
+      bf16x8 ah[NTI], am[NTI], al2[NTI];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NTI; ++i) {
         const int off = ks * 2 * PR + i * 32;
         ah[i] = ap[off]; am[i] = ap[2 * KS * PR + off]; al2[i] = ap[2 * 2 * KS * PR + off];
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i] = pir_mfma_x3(ah[i], am[i], al2[i], f[ks].hi, f[ks].mid, f[ks].lo, acc[i]);
+      for (int i = 0; i < NTI; ++i) acc[i] = pir_mfma_x3(ah[i], am[i], al2[i], f[ks].hi, f[ks].mid, f[ks].lo, acc[i]);
     }
     const int vo = lrow + (bk * 32 + 4 * qk) * 4;
 #pragma unroll
-    for (int e = 0; e < 6; ++e) {
+    for (int e = 0; e < NG; ++e) {
       const int i = e >> 2, G = e & 3;
       float a0 = acc[i][4 * G], a1 = acc[i][4 * G + 1], a2 = acc[i][4 * G + 2], a3 = acc[i][4 * G + 3];
       res_transpose4(a0, a1, a2, a3);
@@ -156,37 +159,54 @@ void mdta_dqk_kernel(DqkArgs p) {
   load(qrs, blk, qr);
   load(krs, blk, kr);
   __builtin_amdgcn_sched_barrier(0);
-  for (; blk < end; blk += 8) {
-    // the next block's planes fly while this one is multiplied (a wave's 12 KB stay in flight through its MFMAs)
-    f32x4 qn[KS][2], kn[KS][2];
-    const int nb = blk + 8 < end ? blk + 8 : blk;
-    load(qrs, nb, qn);
-    load(krs, nb, kn);
-    __builtin_amdgcn_sched_barrier(0);
-    DFrag3 f[KS];
-    frags(kr, f);
-    product(0, f, qr, aq, dqrs, blk);        // dq = dG k + alpha_q q
-    frags(qr, f);
-    product(1, f, kr, ak, dkrs, blk);        // dk = dG^T q + alpha_k k
-    __builtin_amdgcn_sched_barrier(0);
+  for (; blk < end; blk += NW) {
+    if constexpr (PF) {
+      // the next block's planes fly while this one is multiplied (a wave's 12 KB stay in flight through its MFMAs)
+      f32x4 qn[KS][2], kn[KS][2];
+      const int nb = blk + NW < end ? blk + NW : blk;
+      load(qrs, nb, qn);
+      load(krs, nb, kn);
+      __builtin_amdgcn_sched_barrier(0);
+      DFrag3 f[KS];
+      frags(kr, f);
+      product(0, f, qr, aq, dqrs, blk);        // dq = dG k + alpha_q q
+      frags(qr, f);
+      product(1, f, kr, ak, dkrs, blk);        // dk = dG^T q + alpha_k k
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) { qr[ks][t] = qn[ks][t]; kr[ks][t] = kn[ks][t]; }
+        for (int t = 0; t < 2; ++t) { qr[ks][t] = qn[ks][t]; kr[ks][t] = kn[ks][t]; }
+    } else {
+      DFrag3 f[KS];
+      frags(kr, f);
+      product(0, f, qr, aq, dqrs, blk);
+      frags(qr, f);
+      product(1, f, kr, ak, dkrs, blk);
+      if (blk + NW < end) { load(qrs, blk + NW, qr); load(krs, blk + NW, kr); }
+    }
   }
 }
 
+int g_dqk96 = 1;   // knob 36: 0 = the 96-row variant off (two GEMMs)
+
 }  // namespace
+
+int pir_mdta_dqk_tune(int knob, int value) {
+  if (knob == 36) { g_dqk96 = value; return PIR_OK; }
+  return PIR_EINVAL;
+}
 
 extern "C" int pir_mdta_dqk(const float* dgram, const float* q, long q_bs, long k_off, const float* alpha_q,
                             const float* alpha_k, float* dq, long dq_bs, long dk_off, int B, int heads, int c, int HW,
                             pir_stream_t stream) {
   PIR_CHECK_ARG(dgram && q && alpha_q && alpha_k && dq && B > 0 && heads > 0 && HW > 0);
-  // served: 48 rows per head, whole 32-pixel blocks, 16-byte aligned planes; the caller keeps the two-GEMM path otherwise
-  if (c != C48 || HW % 32 != 0) return 1000;
+  // served: 48 or 96 rows per head, whole 32-pixel blocks, 16-byte aligned planes; the caller keeps the two-GEMM path otherwise
+  if ((c != 48 && c != 96) || HW % 32 != 0) return 1000;
+  if (c == 96 && !g_dqk96) return 1000;
   if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(dq)) & 15) return 1000;
   if (q_bs % 4 || k_off % 4 || dq_bs % 4 || dk_off % 4) return 1000;
-  if ((long)C48 * HW * 4 >= (1L << 31) || (long)B * heads > 65535) return 1000;
+  if ((long)c * HW * 4 >= (1L << 31) || (long)B * heads > 65535) return 1000;
   DqkArgs a;
   a.dgram = dgram; a.q = q; a.q_bs = q_bs; a.k_off = k_off; a.alpha_q = alpha_q; a.alpha_k = alpha_k;
   a.dq = dq; a.dq_bs = dq_bs; a.dk_off = dk_off; a.heads = heads; a.HW = HW;
@@ -194,10 +214,13 @@ extern "C" int pir_mdta_dqk(const float* dgram, const float* q, long q_bs, long 
   const long pairs = (long)B * heads;
   long nch = 2L * PIR_NUM_CU / pairs;                        // about two workgroups per CU in flight
   if (nch < 1) nch = 1;
-  const long max_ch = pir_cdiv(a.nblocks, 8);
+  const int nw = c == 96 ? 4 : 8;
+  if (c == 96) nch = (long)PIR_NUM_CU / pairs > 0 ? (long)PIR_NUM_CU / pairs : 1;   // 110 KB of panels: one workgroup per CU
+  const long max_ch = pir_cdiv(a.nblocks, nw);
   if (nch > max_ch) nch = max_ch;
-  a.per_wg = (int)(pir_cdiv(pir_cdiv(a.nblocks, nch), 8) * 8);
+  a.per_wg = (int)(pir_cdiv(pir_cdiv(a.nblocks, nch), nw) * nw);
   const unsigned gx = (unsigned)pir_cdiv(a.nblocks, a.per_wg);
-  hipLaunchKernelGGL(mdta_dqk_kernel, dim3(gx, (unsigned)pairs), dim3(512), 0, (hipStream_t)stream, a);
+  if (c == 96) hipLaunchKernelGGL((mdta_dqk_kernel<96, 6, 96, 4, true>), dim3(gx, (unsigned)pairs), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((mdta_dqk_kernel<48, 3, 64, 8, true>), dim3(gx, (unsigned)pairs), dim3(512), 0, (hipStream_t)stream, a);
   return pir_launch_status();
 }

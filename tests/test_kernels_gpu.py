@@ -540,7 +540,8 @@ def test_pixel_shuffles(b, c, h, w):
     assert torch.equal(ops.pixel_shuffle(lo).cpu(), hi)               # round trip
 
 
-@pytest.mark.parametrize("heads,c,hw", [(1, 48, 256), (2, 48, 99), (4, 176, 64), (4, 40, 128), (8, 48, 16)])
+@pytest.mark.parametrize("heads,c,hw", [(1, 48, 256), (2, 48, 99), (4, 176, 64), (4, 40, 128), (8, 48, 16), (1, 96, 256), (1, 96, 1056),
+                                         (2, 96, 64)])
 def test_mdta_core(heads, c, hw):
     from promptir_amd import ops
 
