@@ -253,3 +253,28 @@ def test_gemm_plan_reaches_the_tuned_tiles_for_config3_shapes():
     assert plan(0, 1, 1, 1) == -22
     # operands beyond the 32-bit byte offsets of the bf16x3 kernel fall back to the fp32 kernel
     assert plan(96, 255, 2200 * 2048, 1) == 0
+
+
+def test_part_batch_rule_and_new_entry_points_are_declared():
+    """Host logic of round 4 that needs no GPU: how a batch is cut into part streams, and that the header, the binding
+    and the library agree on the entry points added this round."""
+    from promptir_amd import _lib
+    from promptir_amd.train import DataParallelTrainer
+
+    tr = DataParallelTrainer.__new__(DataParallelTrainer)
+    tr.micro_streams, tr.min_part = 2, 0
+    assert [tr._nparts(b) for b in (1, 4, 7, 8, 16, 32)] == [1, 1, 1, 2, 2, 2]
+    tr.micro_streams = 4
+    assert [tr._nparts(b) for b in (4, 8, 16, 24, 32, 64)] == [1, 2, 2, 3, 4, 4]
+    tr.min_part = 2                                   # PIR_MIN_PART override
+    assert tr._nparts(8) == 4
+    names = set(_declared())
+    for fn in ("pir_reduce_defer", "pir_reduce_flush", "pir_reduce_pending", "pir_reduce_defer_limit", "pir_gemm_nt_group",
+               "pir_gemm_nt_ws_needed", "pir_gemm_nt_group_ws_needed", "pir_copy_strided4", "pir_crop_augment_u8",
+               "pir_gdfn_fused_fwd", "pir_gdfn_fused_ws_bytes"):
+        assert fn in names and fn in _lib.SIGNATURES, fn
+    # host-only queries answer without a device
+    assert _lib.lib.pir_reduce_defer_limit(-1) == 4 << 20
+    assert _lib.lib.pir_reduce_pending(None) == 0
+    assert _lib.lib.pir_gdfn_fused_ws_bytes(2, 96, 128, 128) == 2 * 128 * 128 * 96 * 6
+    assert _lib.lib.pir_gemm_nt_ws_needed(None) == 0
