@@ -81,6 +81,7 @@ struct FusedArgs {
   int hid, H, W;
   int band;                   // output rows per workgroup; each band re-multiplies one input row above and below
   int nchunks, nbands, B;     // ceil(hid / 32), bands per image, images
+  float* dump;                // 16 KB the pipelined kernel's non-storing lanes write to (keeps its row step branch-free)
 };
 
 // FAST = false: libm erff, the arithmetic of the unfused forward (pir_dwconv3x3_gate); FAST = true: Abramowitz & Stegun
@@ -280,18 +281,199 @@ void gdfn_fused_kernel(FusedArgs a) {
   if (r <= rend) row_step(r, accA, accB);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Pipelined form (knob 37): ONE wave per SIMD with the whole register file.  The product of row r + 1 is issued INSIDE the
+// filter / gate arithmetic of row r (same basic block, interleaved by scheduling groups: one MFMA per ~8 vector
+// instructions), the fragments of row r + 2 are in flight meanwhile: nothing waits on memory or on the matrix pipe in
+// steady state.  Fragment sets, products and pending rows swap roles every row (loop unrolled by two).
+template <int KS, int NWV, bool FAST>
+__global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(1)))
+void gdfn_fused_pipe_kernel(FusedArgs a) {
+  constexpr int T = NWV * 64;
+  constexpr int PUNITS = 3 * KS * 2 * 64;
+  __shared__ bf16x8 panel[PUNITS];
+  __shared__ float edge[2][2][2][NWV][32];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, cl = lane & 31;
+  const int lin = (int)blockIdx.x, xcd = lin & 7, t = lin >> 3;
+  const int q = t % a.nchunks, unit = (t / a.nchunks) * 8 + xcd;
+  if (unit >= a.B * a.nbands) return;
+  const int b = unit / a.nbands, band_i = unit - b * a.nbands;
+  const int hid = a.hid, H = a.H, W = a.W, M = 2 * hid;
+  const int npairs = hid - 32 * q < 32 ? hid - 32 * q : 32;
+  for (int u = tid; u < PUNITS; u += T) {
+    const int row = u & 63, hh = (u >> 6) & 1, rest = u >> 7;
+    const int i = row & 31;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+    if (i < npairs) {
+      const int m = (row < 32 ? 0 : hid) + 32 * q + i;
+      v = a.w3[((long)rest * M + m) * 2 + hh];
+    }
+    panel[u] = v;
+  }
+  const bool live = cl < npairs;
+  const int c1 = 32 * q + (live ? cl : 0), c2 = hid + c1;
+  float t1[9], t2[9];
+#pragma unroll
+  for (int e = 0; e < 9; ++e) { t1[e] = live ? a.wd[c1 * 9 + e] : 0.f; t2[e] = live ? a.wd[c2 * 9 + e] : 0.f; }
+  __syncthreads();
+
+  const bf16x8* __restrict__ xbase = a.xn3 + ((long)b * H * NWV + wid) * KS * 3 * 64 + lane;
+  const long row_units = (long)NWV * KS * 3 * 64;
+  float* __restrict__ gout = a.g + (long)b * a.g_bs + (long)c1 * H * W + 32 * wid + 4 * h;
+  const int r0 = band_i * a.band, r1 = r0 + a.band < H ? r0 + a.band : H;
+  const int rs = r0 > 0 ? r0 - 1 : 0;
+  const int rend = r1 == H ? H : r1;
+  const int rlast = rend < H ? rend : H - 1;                 // last input row of the band
+  const bool hb = h != 0;
+
+  auto load_row = [&](int r, bf16x8 (&f)[KS][3]) {
+    const bf16x8* __restrict__ p = xbase + (long)r * row_units;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) f[ks][pc] = p[(ks * 3 + pc) * 64];
+  };
+  auto product = [&](const bf16x8 (&f)[KS][3], f32x16 (&d)[2], int opaque) {
+    const bf16x8* wp = panel + h * 64 + cl + (opaque >> 30);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int p = 0; p < 16; ++p) d[nb][p] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 bw[2][3];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) bw[nb][pc] = wp[((pc * KS + ks) * 2) * 64 + nb * 32];
+#define PIR_GF_TERM(A_, B_) _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) \
+      d[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks][A_], bw[nb][B_], d[nb], 0, 0, 0);
+      PIR_GF_TERM(2, 0) PIR_GF_TERM(0, 2) PIR_GF_TERM(1, 1) PIR_GF_TERM(1, 0) PIR_GF_TERM(0, 1) PIR_GF_TERM(0, 0)
+#undef PIR_GF_TERM
+    }
+  };
+
+  bf16x8 fa[KS][3], fb[KS][3];
+  f32x16 da[2], db[2];
+  float accA[2][16], accB[2][16];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int p = 0; p < 16; ++p) { accA[nb][p] = 0.f; accB[nb][p] = 0.f; }
+  load_row(rs, fa);
+  load_row(rs + 1 <= rlast ? rs + 1 : rs, fb);
+  product(fa, da, rs);                                       // the band's first row: nothing to hide it under
+
+  // D: product of row r (zeros in the flush iteration); DN <- product of row r + 1 from FN; FL <- fragments of row r + 2
+  auto step = [&](int r, f32x16 (&D)[2], f32x16 (&DN)[2], const bf16x8 (&FN)[KS][3], bf16x8 (&FL)[KS][3],
+                  float (&P)[2][16], float (&Q)[2][16]) {
+    const int par = r & 1;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) edge[par][nb][h][wid][cl] = hb ? D[nb][15] : D[nb][0];
+    __syncthreads();
+    load_row(r + 2 <= rlast ? r + 2 : rlast, FL);            // (past the band: the last row again, unused)
+    __builtin_amdgcn_sched_barrier(0);
+    product(FN, DN, r);                                      // row r + 1 (past the band: discarded below)
+    float lft[2][4], rgt[2][4];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      float rf[4], rl[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        rf[j] = __shfl_xor(D[nb][4 * j], 32, 64);
+        rl[j] = __shfl_xor(D[nb][4 * j + 3], 32, 64);
+      }
+      const float eL = wid > 0 ? edge[par][nb][1][wid > 0 ? wid - 1 : 0][cl] : 0.f;
+      const float eR = wid + 1 < NWV ? edge[par][nb][0][wid + 1 < NWV ? wid + 1 : wid][cl] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        lft[nb][j] = hb ? rl[j] : (j > 0 ? rl[j > 0 ? j - 1 : 0] : eL);
+        rgt[nb][j] = hb ? (j < 3 ? rf[j < 3 ? j + 1 : 3] : eR) : rf[j];
+      }
+    }
+    const bool store = r - 1 >= r0 && r - 1 < r1 && live;
+    // lanes that must not store (rows outside the band, lanes beyond the last gate pair) write into a dump area instead: no
+    // branch inside the interleaved region
+    float* __restrict__ dst = store ? gout + (long)(r - 1) * W : a.dump + tid * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x2 l2[2][2], m2[2][2], r2[2][2];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const float a0 = D[nb][4 * j], a1 = D[nb][4 * j + 1], a2 = D[nb][4 * j + 2], a3 = D[nb][4 * j + 3];
+        l2[nb][0] = f32x2{lft[nb][j], a0}; m2[nb][0] = f32x2{a0, a1}; r2[nb][0] = f32x2{a1, a2};
+        l2[nb][1] = f32x2{a1, a2};         m2[nb][1] = f32x2{a2, a3}; r2[nb][1] = f32x2{a3, rgt[nb][j]};
+      }
+      f32x2 fin[2][2];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const float (&tp)[9] = nb == 0 ? t1 : t2;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int p = 4 * j + 2 * k;
+          f32x2 o = f32x2{P[nb][p], P[nb][p + 1]};
+          o = __builtin_elementwise_fma(f32x2{tp[6], tp[6]}, l2[nb][k], o);
+          o = __builtin_elementwise_fma(f32x2{tp[7], tp[7]}, m2[nb][k], o);
+          o = __builtin_elementwise_fma(f32x2{tp[8], tp[8]}, r2[nb][k], o);
+          fin[nb][k] = o;
+          f32x2 q2 = f32x2{Q[nb][p], Q[nb][p + 1]};
+          q2 = __builtin_elementwise_fma(f32x2{tp[3], tp[3]}, l2[nb][k], q2);
+          q2 = __builtin_elementwise_fma(f32x2{tp[4], tp[4]}, m2[nb][k], q2);
+          q2 = __builtin_elementwise_fma(f32x2{tp[5], tp[5]}, r2[nb][k], q2);
+          Q[nb][p] = q2[0]; Q[nb][p + 1] = q2[1];
+          f32x2 n2 = f32x2{tp[0], tp[0]} * l2[nb][k];
+          n2 = __builtin_elementwise_fma(f32x2{tp[1], tp[1]}, m2[nb][k], n2);
+          n2 = __builtin_elementwise_fma(f32x2{tp[2], tp[2]}, r2[nb][k], n2);
+          P[nb][p] = n2[0]; P[nb][p + 1] = n2[1];
+        }
+      }
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f<FAST>(fin[0][e >> 1][e & 1]) * fin[1][e >> 1][e & 1];
+      *reinterpret_cast<f32x4*>(dst + (store ? 8 * j : 4 * j)) = v;
+    }
+    // one MFMA per ~8 vector instructions, the panel reads ahead of their MFMAs
+#pragma unroll
+    for (int m = 0; m < 6 * KS; ++m) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, FAST ? 7 : 12, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, FAST ? 7 : 12, 0);
+    }
+    if (!(r + 1 <= rlast)) {                                 // no row r + 1 in this band: the flush iteration sees zeros
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int p = 0; p < 16; ++p) DN[nb][p] = 0.f;
+    }
+  };
+
+  int r = rs;
+  for (; r + 1 <= rend; r += 2) {
+    step(r, da, db, fb, fa, accA, accB);
+    step(r + 1, db, da, fa, fb, accB, accA);
+  }
+  if (r <= rend) step(r, da, db, fb, fa, accA, accB);
+}
+
 int g_fused_fast_erf = 0;   // knob 35: 1 = the backward kernels' erf approximation in the fused forward gate (default: libm erff)
+int g_fused_pipe = 0;       // knob 37: 1 = the pipelined one-wave-per-SIMD kernel
 
 }  // namespace
 
 int pir_gdfn_fused_tune(int knob, int value) {
   if (knob == 35) { g_fused_fast_erf = value; return PIR_OK; }
+  if (knob == 37) { g_fused_pipe = value; return PIR_OK; }
   return PIR_EINVAL;
 }
 
 extern "C" size_t pir_gdfn_fused_ws_bytes(int B, int C, int H, int W) {
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
-  return (size_t)B * H * W * C * 6;
+  return (size_t)B * H * W * C * 6 + 16384;      // fragments + the pipelined kernel's dump area
 }
 
 // g = gelu(dw3x3(W_in LN(x))[:hid]) * dw3x3(W_in LN(x))[hid:] with h0 never in memory.  w3: pir_split_bf16x3 pieces of W_in
@@ -316,6 +498,7 @@ extern "C" int pir_gdfn_fused_fwd(const float* x, long x_bs, const float* ln_w, 
   if (st) return st;
   FusedArgs a;
   a.xn3 = xn3; a.w3 = reinterpret_cast<const bf16x8*>(w3); a.wd = wd; a.g = g; a.g_bs = g_bs; a.hid = hid; a.H = H; a.W = W;
+  a.dump = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)B * H * W * C * 6);
   // bands of output rows: enough workgroups for two per CU (a workgroup is one wave per SIMD); each band re-multiplies
   // two halo rows, so no band is shorter than 16 rows (12 % recompute)
   const long base = pir_cdiv(hid, 32) * (long)B;
@@ -326,8 +509,11 @@ extern "C" int pir_gdfn_fused_fwd(const float* x, long x_bs, const float* ln_w, 
   a.nchunks = (int)pir_cdiv(hid, 32); a.nbands = (int)pir_cdiv(H, a.band); a.B = B;
   const long units = (long)B * a.nbands;
   const dim3 grid((unsigned)(pir_cdiv(units, 8) * 8 * a.nchunks));
-#define PIR_GF(KS_, NW_) do { if (g_fused_fast_erf) hipLaunchKernelGGL((gdfn_fused_kernel<KS_, NW_, true>), grid, dim3(NW_ * 64), 0, s, a); \
-                             else hipLaunchKernelGGL((gdfn_fused_kernel<KS_, NW_, false>), grid, dim3(NW_ * 64), 0, s, a); } while (0)
+#define PIR_GF(KS_, NW_) do { \
+    if (g_fused_pipe && g_fused_fast_erf) hipLaunchKernelGGL((gdfn_fused_pipe_kernel<KS_, NW_, true>), grid, dim3(NW_ * 64), 0, s, a); \
+    else if (g_fused_pipe) hipLaunchKernelGGL((gdfn_fused_pipe_kernel<KS_, NW_, false>), grid, dim3(NW_ * 64), 0, s, a); \
+    else if (g_fused_fast_erf) hipLaunchKernelGGL((gdfn_fused_kernel<KS_, NW_, true>), grid, dim3(NW_ * 64), 0, s, a); \
+    else hipLaunchKernelGGL((gdfn_fused_kernel<KS_, NW_, false>), grid, dim3(NW_ * 64), 0, s, a); } while (0)
   if (C == 96 && W == 128) PIR_GF(6, 4);
   else if (C == 96) PIR_GF(6, 2);
   else if (W == 128) PIR_GF(3, 4);

@@ -970,7 +970,7 @@ extern "C" int pir_tune_set(int knob, int value) {
     case 14: g_nt_quad = value; return PIR_OK;
     case 33: g_nt_tile96 = value; return PIR_OK;
     case 34: g_nt_group_wide = value; return PIR_OK;
-    case 35: return pir_gdfn_fused_tune(knob, value);
+    case 35: case 37: return pir_gdfn_fused_tune(knob, value);
     case 36: return pir_mdta_dqk_tune(knob, value);
     case 19: g_nt_want_half = value; return PIR_OK;
     case 20: return pir_nn_res_tune(knob, value);

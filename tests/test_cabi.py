@@ -276,5 +276,5 @@ def test_part_batch_rule_and_new_entry_points_are_declared():
     # host-only queries answer without a device
     assert _lib.lib.pir_reduce_defer_limit(-1) == 4 << 20
     assert _lib.lib.pir_reduce_pending(None) == 0
-    assert _lib.lib.pir_gdfn_fused_ws_bytes(2, 96, 128, 128) == 2 * 128 * 128 * 96 * 6
+    assert _lib.lib.pir_gdfn_fused_ws_bytes(2, 96, 128, 128) == 2 * 128 * 128 * 96 * 6 + 16384
     assert _lib.lib.pir_gemm_nt_ws_needed(None) == 0
