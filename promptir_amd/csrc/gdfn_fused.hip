@@ -328,6 +328,7 @@ void gdfn_fused_pipe_kernel(FusedArgs a) {
   const int rend = r1 == H ? H : r1;
   const int rlast = rend < H ? rend : H - 1;                 // last input row of the band
   const bool hb = h != 0;
+  const float maskL = wid > 0 ? 1.f : 0.f, maskR = wid + 1 < NWV ? 1.f : 0.f;     // zero padding at the image's left / right border
 
   auto load_row = [&](int r, bf16x8 (&f)[KS][3]) {
     const bf16x8* __restrict__ p = xbase + (long)r * row_units;
@@ -386,8 +387,10 @@ void gdfn_fused_pipe_kernel(FusedArgs a) {
         rf[j] = __shfl_xor(D[nb][4 * j], 32, 64);
         rl[j] = __shfl_xor(D[nb][4 * j + 3], 32, 64);
       }
-      const float eL = wid > 0 ? edge[par][nb][1][wid > 0 ? wid - 1 : 0][cl] : 0.f;
-      const float eR = wid + 1 < NWV ? edge[par][nb][0][wid + 1 < NWV ? wid + 1 : wid][cl] : 0.f;
+      // (multiplied by a 0 / 1 factor instead of selected: a wave-uniform condition would become a scalar BRANCH around the
+      // load and cut the row step into several scheduling regions - the MFMAs could then not be interleaved with the filter)
+      const float eL = edge[par][nb][1][wid > 0 ? wid - 1 : 0][cl] * maskL;
+      const float eR = edge[par][nb][0][wid + 1 < NWV ? wid + 1 : wid][cl] * maskR;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         lft[nb][j] = hb ? rl[j] : (j > 0 ? rl[j > 0 ? j - 1 : 0] : eL);

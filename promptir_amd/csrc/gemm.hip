@@ -975,7 +975,7 @@ extern "C" int pir_tune_set(int knob, int value) {
     case 19: g_nt_want_half = value; return PIR_OK;
     case 20: return pir_nn_res_tune(knob, value);
     case 21: case 22: case 23: case 24: return pir_nn_res_tune2(knob, value);
-    case 25: return pir_nt_xp_tune(knob, value);
+    case 25: case 38: case 40: return pir_nt_xp_tune(knob, value);
     case 26: case 27: case 32: return pir_nn_cst_tune(knob, value);
     case 30: return pir_conv_rows_tune(knob, value);
     default: return PIR_EINVAL;

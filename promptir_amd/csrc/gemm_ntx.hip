@@ -52,7 +52,15 @@ struct XpArgs {
 
 // RBW: 32-row blocks of X per wave; TN: 32-column blocks of the output (ceil(M2 / 32)); the number of waves is the
 // launch's (rowblocks / RBW rounded up)
-template <int RBW, int TN, bool YLN = false>
+// GRP: the four 16-byte loads that make up a lane's 64-byte run of a row (and, with the partner lane half, the row's whole
+// 128-byte line of the step) are issued BACK TO BACK instead of half a step apart.  Issued apart, every line is touched at
+// two times ~1 us apart with 64 - 128 KB of other lines per CU in between - rows lie a power of two apart (one image
+// plane), so they compete for a few cache sets - and the counters showed 1.6 - 2.2x the algorithmic bytes FETCHED from
+// memory (profiles/r04_pmc_summary.txt: 2 x 557 MB against 635 MB for the 510 x 96 weight gradient, which ran at 6.2 TB/s
+// of real traffic).  One row block per wave: a second register set, loaded a whole step ahead.  Two row blocks: the units
+// run block-major, (e, m) instead of (m, e), so that all registers of a block are free at its second unit and are
+// refilled there in one go, two units ahead of their use.
+template <int RBW, int TN, bool YLN = false, bool GRP = false>
 __global__ __launch_bounds__(RBW == 2 ? 512 : 576) __attribute__((amdgpu_waves_per_eu(2)))
 void gemm_nt_xp_kernel(XpArgs p) {
   constexpr int YR = TN * 32;             // rows of the shared operand held per stage (padded)
@@ -130,7 +138,42 @@ void gemm_nt_xp_kernel(XpArgs p) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[e][c][q] = 0.f;
 
-  if constexpr (RBW == 1) {
+  if constexpr (RBW == 1 && GRP) {
+    // one row block per wave, two register sets: the whole next step is requested at the top of the current one
+    f32x4 xb[4];
+    auto step = [&](int s, f32x4 (&cur)[4], f32x4 (&nxt)[4]) {
+      const int buf = (s - s_begin) & 1;
+      const float *xn, *yn;
+      base(s + 1, xn, yn);            // (the step after the last one re-reads the last: unused)
+      const bf16x8* bp = smem + buf * STAGE + h * YR + r + ((s - s_begin) >> 30);   // opaque zero: see gemm_res.hip
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) nxt[q] = *reinterpret_cast<const f32x4*>(xn + xoff[0] + 4 * q);
+      yr[0] = *reinterpret_cast<const f32x4*>(yn + yoff);
+      yr[1] = *reinterpret_cast<const f32x4*>(yn + yoff + 4);
+      load_stats();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const XFrag3 cf = xp_split8(cur[2 * m], cur[2 * m + 1]);
+#pragma unroll
+        for (int c = 0; c < TN; ++c) {
+          const bf16x8 bh = bp[m * 2 * YR + c * 32], bm = bp[YU + m * 2 * YR + c * 32], bl = bp[2 * YU + m * 2 * YR + c * 32];
+          acc[0][c] = pir_mfma_x3(cf.hi, cf.mid, cf.lo, bh, bm, bl, acc[0][c]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {   // the next step's slice of the shared operand into the other buffer
+        const XFrag3 f = ysplit(yr[0], yr[1]);
+        bf16x8* dst = smem + (buf ^ 1) * STAGE;
+        if (yact) { dst[ydst] = f.hi; dst[YU + ydst] = f.mid; dst[2 * YU + ydst] = f.lo; }
+      }
+      __syncthreads();
+    };
+    int s = s_begin;
+    for (; s + 1 < s_end; s += 2) { step(s, xr[0], xb); step(s + 1, xb, xr[0]); }
+    if (s < s_end) step(s, xr[0], xb);
+  } else if constexpr (RBW == 1) {
     // one row block per wave: conversion, refill of the consumed registers with the NEXT step's pixels (a whole step
     // ahead), multiply
     for (int s = s_begin; s < s_end; ++s) {
@@ -163,6 +206,58 @@ void gemm_nt_xp_kernel(XpArgs p) {
       }
       __syncthreads();
     }
+  } else if constexpr (GRP) {
+  // block-major units u = (step, e, m): conversion of unit u + 1 in the shadow of unit u's MFMAs as below; at a block's
+  // second unit (m = 1) all of its raw registers have been converted and the block's whole next step is requested
+  XFrag3 xf = xp_split8(xr[0][0], xr[0][1]);
+  for (int s = s_begin; s < s_end; ++s) {
+    const int buf = (s - s_begin) & 1;
+    const float *xn, *yn;
+    base(s + 1, xn, yn);            // (the step after the last one re-reads the last: unused)
+    const bf16x8* bp = smem + buf * STAGE + h * YR + r + ((s - s_begin) >> 30);   // opaque zero: see gemm_res.hip
+#pragma unroll
+    for (int e = 0; e < RBW; ++e) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 bh[TN], bm[TN], bl[TN];
+#pragma unroll
+        for (int c = 0; c < TN; ++c) { bh[c] = bp[m * 2 * YR + c * 32]; bm[c] = bp[YU + m * 2 * YR + c * 32]; bl[c] = bp[2 * YU + m * 2 * YR + c * 32]; }
+        const XFrag3 cur = xf;
+        if (m == 1) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xr[e][q] = *reinterpret_cast<const f32x4*>(xn + xoff[e] + 4 * q);
+        }
+        if (m == 0 && e == 0) {
+          yr[0] = *reinterpret_cast<const f32x4*>(yn + yoff);
+          yr[1] = *reinterpret_cast<const f32x4*>(yn + yoff + 4);
+          load_stats();
+        }
+        // next unit: (e, 1), (e + 1, 0) or the next step's (0, 0) - whose registers were refilled two units ago
+        const int ne = m == 0 ? e : (e + 1 < RBW ? e + 1 : 0), nm = m ^ 1;
+        xf = xp_split8(xr[ne][2 * nm], xr[ne][2 * nm + 1]);
+#pragma unroll
+        for (int c = 0; c < TN; ++c) acc[e][c] = pir_mfma_x3(cur.hi, cur.mid, cur.lo, bh[c], bm[c], bl[c], acc[e][c]);
+        constexpr int NV = 0;
+        (void)NV;
+        __builtin_amdgcn_sched_group_barrier(0x100, 3 * TN, 0);
+        const int nvm = (m == 1 ? 4 : 0) + ((m == 0 && e == 0) ? (YLN ? 6 : 2) : 0);
+#pragma unroll
+        for (int q = 0; q < 6 * TN; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (q < nvm) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, (96 + 6 * TN - 1) / (6 * TN), 0);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {   // the next step's slice of the shared operand into the other buffer
+      const XFrag3 f = ysplit(yr[0], yr[1]);
+      bf16x8* dst = smem + (buf ^ 1) * STAGE;
+      if (yact) { dst[ydst] = f.hi; dst[YU + ydst] = f.mid; dst[2 * YU + ydst] = f.lo; }
+    }
+    __syncthreads();
+  }
   } else {
   // Software pipeline over units u = (step, m, row block e): while the 6 x TN MFMAs of unit u run, the conversion of
   // unit u + 1's eight pixels per lane is issued in their shadow (the waves of a workgroup run in lockstep from the
@@ -237,6 +332,9 @@ void gemm_nt_xp_kernel(XpArgs p) {
 }
 
 int g_xp_mode = -1;   // knob 25: -1 automatic, 0 never, 1 whenever the shape is served
+int g_xp_rbw2_min = 10;   // knob 40: row blocks from which a wave takes two (the software-pipelined kernel)
+int g_xp_grp = 1;     // knob 38: a row's loads of a step issued back to back (GRP): 1 two-row-block kernels only (the one-block kernels
+                      // are not bound by bytes: same-box A/B 1.02 - 1.11 of the half-step refill's time), 2 all, 0 none
 
 struct XpPlan { int rbw, tn, nwv, splits, rowblocks; };
 
@@ -249,7 +347,7 @@ bool xp_plan(const pir_gemm_nt_t& g, XpPlan& pl, bool yln = false) {
   if ((long)g.M1 * g.ldx >= (1L << 31) || (long)g.M2 * g.ldy >= (1L << 31)) return false;   // 32-bit row offsets
   pl.rowblocks = (int)pir_cdiv(g.M1, 32);
   if (pl.rowblocks > 16) return false;
-  pl.rbw = pl.rowblocks > 9 ? 2 : 1;
+  pl.rbw = pl.rowblocks >= g_xp_rbw2_min ? 2 : 1;
   pl.nwv = (int)pir_cdiv(pl.rowblocks, pl.rbw);
   if (pl.rbw == 2 && pl.nwv > 8) return false;            // (RBW = 2 kernels are built for <= 512 threads)
   pl.tn = (int)pir_cdiv(g.M2, 32);
@@ -269,6 +367,8 @@ bool xp_plan(const pir_gemm_nt_t& g, XpPlan& pl, bool yln = false) {
 
 int pir_nt_xp_tune(int knob, int value) {
   if (knob == 25) { g_xp_mode = value; return PIR_OK; }
+  if (knob == 38) { g_xp_grp = value; return PIR_OK; }
+  if (knob == 40) { g_xp_rbw2_min = value; return PIR_OK; }
   return PIR_EINVAL;
 }
 
@@ -291,18 +391,23 @@ int pir_nt_xp_launch(const pir_gemm_nt_t* a, int* splits, hipStream_t s, const f
   xa.steps_per_r = a->N / 32;
   xa.rowblocks = pl.rowblocks;
   const dim3 grid((unsigned)pl.splits), block((unsigned)pl.nwv * 64);
+#define PIR_XP_GO(RBW_, TN_, YLN_)                                                                         \
+  do {                                                                                                     \
+    if (g_xp_grp >= 2 || (g_xp_grp == 1 && RBW_ == 2)) hipLaunchKernelGGL((gemm_nt_xp_kernel<RBW_, TN_, YLN_, true>), grid, block, 0, s, xa);   \
+    else hipLaunchKernelGGL((gemm_nt_xp_kernel<RBW_, TN_, YLN_, false>), grid, block, 0, s, xa);           \
+  } while (0)
   if (y_mean) {
-    if (pl.rbw == 2 && pl.tn == 3) hipLaunchKernelGGL((gemm_nt_xp_kernel<2, 3, true>), grid, block, 0, s, xa);
-    else if (pl.rbw == 2) hipLaunchKernelGGL((gemm_nt_xp_kernel<2, 2, true>), grid, block, 0, s, xa);
-    else if (pl.tn == 3) hipLaunchKernelGGL((gemm_nt_xp_kernel<1, 3, true>), grid, block, 0, s, xa);
-    else hipLaunchKernelGGL((gemm_nt_xp_kernel<1, 2, true>), grid, block, 0, s, xa);
-    *splits = pl.splits;
-    return pir_launch_status();
+    if (pl.rbw == 2 && pl.tn == 3) PIR_XP_GO(2, 3, true);
+    else if (pl.rbw == 2) PIR_XP_GO(2, 2, true);
+    else if (pl.tn == 3) PIR_XP_GO(1, 3, true);
+    else PIR_XP_GO(1, 2, true);
+  } else {
+    if (pl.rbw == 2 && pl.tn == 3) PIR_XP_GO(2, 3, false);
+    else if (pl.rbw == 2) PIR_XP_GO(2, 2, false);
+    else if (pl.tn == 3) PIR_XP_GO(1, 3, false);
+    else PIR_XP_GO(1, 2, false);
   }
-  if (pl.rbw == 2 && pl.tn == 3) hipLaunchKernelGGL((gemm_nt_xp_kernel<2, 3>), grid, block, 0, s, xa);
-  else if (pl.rbw == 2) hipLaunchKernelGGL((gemm_nt_xp_kernel<2, 2>), grid, block, 0, s, xa);
-  else if (pl.tn == 3) hipLaunchKernelGGL((gemm_nt_xp_kernel<1, 3>), grid, block, 0, s, xa);
-  else hipLaunchKernelGGL((gemm_nt_xp_kernel<1, 2>), grid, block, 0, s, xa);
+#undef PIR_XP_GO
   *splits = pl.splits;
   return pir_launch_status();
 }

@@ -245,6 +245,7 @@ class DataParallelTrainer:
             # launches - 6211 instead of 3131 per step - and two more flat gradient buffers; the default stays at two)
             micro_streams = int(os.environ.get("PIR_MICRO_STREAMS", "2" if self.graph else "1"))
         self.micro_streams = max(1, micro_streams) if self.opt.param.is_cuda else 1
+        self.stagger_us = int(os.environ.get("PIR_STAGGER_US", "0"))
         self.min_part = max(0, int(os.environ.get("PIR_MIN_PART", "0")))     # 0: the rule of _nparts
         self._split_sig = None
         self._seg_state = None
@@ -336,6 +337,8 @@ class DataParallelTrainer:
             st.wait_event(ready)
             self._use_sinks(i)                       # captured by the autograd nodes of this forward
             with torch.cuda.stream(st):
+                if i and self.stagger_us:            # part streams offset against each other (PIR_STAGGER_US)
+                    ops.delay_us(i * self.stagger_us)
                 losses.append(self._part_loss(self.net(degrad_patch[lo:hi]), clean_patch[lo:hi], (hi - lo) / b))
         for i, (loss, w) in enumerate(losses):
             with torch.cuda.stream(self._streams[i]):
