@@ -440,7 +440,6 @@ def main():
                                    f"({baseline_cfg})",
                        "global_batch": args.batch * world, "patch": args.patch, "parallelism": f"dp{world}",
                        "execution": f"hipGraph={int(trainer.graph)}, part-batch streams={trainer._nparts(args.batch)}" +
-                                    (" (one graph per part, replayed side by side)" if getattr(trainer, "_part_losses", None) is not None else "") +
                                     (", backward in 3 segments with overlapped gradient all-reduce" if trainer.staged else ""),
                        "process_group": dist.get_backend() if dist.is_initialized() else None,
                        "world": world, "device_index": local, "replica_param_spread": spread,

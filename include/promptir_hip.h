@@ -375,10 +375,6 @@ int pir_copy_strided4(const float* x, long s0, long s1, long s2, long s3, float*
                       pir_stream_t stream);
 /* out[i] = a[i] + b[i] */
 int pir_add(const float* a, const float* b, float* out, long count, pir_stream_t stream);
-/* One wave that occupies `stream` for `microseconds` (<= 20000) of the constant 100 MHz clock and does nothing else: the
- * trainer offsets its part-batch streams with it (promptir_amd/train.py, PIR_STAGGER_US; the reference has no counterpart,
- * its two "streams" are DDP ranks, train.py:336-339) so that the streams do not run the same kernel kinds at the same time */
-int pir_delay_us(int microseconds, pir_stream_t stream);
 
 /* Convolution bias, `bias=True` (net/model.py:88-92,111-113,206,294-320; every reference caller passes False):
  *   pir_bias_add   y[b][c][:] += bias[c] in place (after the bias-free convolution kernel)

@@ -109,7 +109,6 @@ SIGNATURES = {
     "pir_crop_augment_u8": (I, [P, P, P, P, P, P, I, I, S]),
     "pir_copy_planes": (I, [P, L, P, L, I, I, L, S]),
     "pir_add": (I, [P, P, P, L, S]),
-    "pir_delay_us": (I, [I, S]),
     "pir_bias_add": (I, [P, L, P, I, I, I, S]),
     "pir_bias_grad": (I, [P, L, P, I, I, I, S]),
     "pir_gelu_gate": (I, [P, L, P, L, I, I, I, S]),

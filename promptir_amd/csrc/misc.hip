@@ -233,21 +233,6 @@ extern "C" int pir_copy_planes(const float* x, long x_bs, float* y, long y_bs, i
   return pir_launch_status();
 }
 
-namespace {
-// exit condition every wave reaches: the 100 MHz wall clock passes the deadline (at most 20 ms after the start)
-__global__ __launch_bounds__(64) void delay_kernel(long ticks) {
-  const long t0 = (long)wall_clock64();
-  while ((long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
-}
-}  // namespace
-
-extern "C" int pir_delay_us(int microseconds, pir_stream_t stream) {
-  PIR_CHECK_ARG(microseconds >= 0 && microseconds <= 20000);
-  if (microseconds == 0) return PIR_OK;
-  hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, 100L * microseconds);
-  return pir_launch_status();
-}
-
 extern "C" int pir_add(const float* a, const float* b, float* out, long count, pir_stream_t stream) {
   PIR_CHECK_ARG(a && b && out && count > 0);
   hipLaunchKernelGGL(add_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, a, b, out, count);

@@ -1733,11 +1733,6 @@ def unit_gradient(device) -> torch.Tensor:
     return t
 
 
-def delay_us(us: int) -> None:
-    """The current stream idles for `us` microseconds (pir_delay_us): offsets between part-batch streams."""
-    check(lib.pir_delay_us(int(us), _stream()), "pir_delay_us")
-
-
 def add_(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """a += b on flat fp32 buffers (pir_add)."""
     _require_gpu(a, b)

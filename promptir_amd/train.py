@@ -245,16 +245,6 @@ class DataParallelTrainer:
             # launches - 6211 instead of 3131 per step - and two more flat gradient buffers; the default stays at two)
             micro_streams = int(os.environ.get("PIR_MICRO_STREAMS", "2" if self.graph else "1"))
         self.micro_streams = max(1, micro_streams) if self.opt.param.is_cuda else 1
-        self.stagger_us = int(os.environ.get("PIR_STAGGER_US", "0"))
-        # One hipGraph PER PART, replayed on the parts' streams at the same time, instead of one graph that forks into the
-        # part streams: a dependent launch costs 1.5 us in a single-chain graph, 3.3 us when two single-chain graphs
-        # run beside each other and 6.0 us per chain inside ONE graph with two branches (tools/launch_floor.py, round 4:
-        # 2000 launches in 3.1 / 3.3 / 6.0 ms) - at ~1550 launches per part stream the forked graph pays ~4 ms more of
-        # launch processing per step than two graphs do.  In the real step that does not show: same-box A/B 92.1 / 91.2 ms
-        # against 91.3 / 91.5 (batch 32) and 36.1 / 35.8 against 35.2 / 35.3 ms (batch 8) - the step's launches are not
-        # bound by the launch floor (their processing overlaps the other stream's kernels).  OPT-IN (PIR_PART_GRAPHS=1).
-        self.part_graphs = os.environ.get("PIR_PART_GRAPHS", "0") != "0"
-        self._part_losses = None
         self.min_part = max(0, int(os.environ.get("PIR_MIN_PART", "0")))     # 0: the rule of _nparts
         self._split_sig = None
         self._seg_state = None
@@ -303,7 +293,7 @@ class DataParallelTrainer:
         three-piece forward)."""
         staged = bool(staged) and self.opt.param.is_cuda and self._staged_ok()
         if staged != self.staged:
-            self.staged, self._graph, self._graph_shape, self._seg_state, self._part_losses = staged, None, None, None, None
+            self.staged, self._graph, self._graph_shape, self._seg_state = staged, None, None, None
         return self.staged
 
     def _use_sinks_default(self) -> None:
@@ -346,8 +336,6 @@ class DataParallelTrainer:
             st.wait_event(ready)
             self._use_sinks(i)                       # captured by the autograd nodes of this forward
             with torch.cuda.stream(st):
-                if i and self.stagger_us:            # part streams offset against each other (PIR_STAGGER_US)
-                    ops.delay_us(i * self.stagger_us)
                 losses.append(self._part_loss(self.net(degrad_patch[lo:hi]), clean_patch[lo:hi], (hi - lo) / b))
         for i, (loss, w) in enumerate(losses):
             with torch.cuda.stream(self._streams[i]):
@@ -521,31 +509,11 @@ class DataParallelTrainer:
                 self._fwd_bwd(self._sx, self._st)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        n, bounds = self._parts(degrad_patch.shape[0])
-        per_part = self.part_graphs and n > 1
-        graph = [torch.cuda.CUDAGraph() for _ in range(n)] if per_part else torch.cuda.CUDAGraph()
+        graph = torch.cuda.CUDAGraph()
         try:
-            if per_part:
-                # every part on ITS stream: workspaces, partial-sum arenas and the library's reduction queues are keyed
-                # by the stream handle, so parts replayed side by side share nothing but the read-only weights
-                from . import ops
-
-                b, losses = degrad_patch.shape[0], []
-                with ops.side_streams(False):
-                    for i in range(n):
-                        lo, hi = bounds[i], bounds[i + 1]
-                        self._use_sinks(i)
-                        with torch.cuda.graph(graph[i], stream=self._streams[i], capture_error_mode="thread_local"):
-                            loss, seed = self._part_loss(self.net(self._sx[lo:hi]), self._st[lo:hi], (hi - lo) / b)
-                            loss.backward(gradient=seed)
-                        losses.append((loss, seed))
-                self._use_sinks(0)
-                self._part_losses, sloss = losses, None
-            else:
-                # thread_local: the RCCL watchdog thread of a multi-GPU job may query its events while this thread captures
-                self._part_losses = None
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    sloss = self._fwd_bwd(self._sx, self._st)
+            # thread_local: the RCCL watchdog thread of a multi-GPU job may query its events while this thread captures
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                sloss = self._fwd_bwd(self._sx, self._st)
         except RuntimeError as exc:
             # Only a capture-specific refusal (the runtime cannot capture / instantiate this stream work) falls back;
             # anything else is re-raised.  torch.cuda.graph.__exit__ has already ended the capture on every stream
@@ -610,36 +578,12 @@ class DataParallelTrainer:
                     between(1)
                 self._graph[2].replay()
                 return loss
-            if self._part_losses is not None:     # one graph per part
-                return self._replay_parts()
             self._graph.replay()
             return self._loss_out()
         if self.staged and ops.lib.records is None:
             return self._staged_eager(degrad_patch, clean_patch, between)
         # eager; the instrumented (per-kernel timed) step stays on one stream
         return self._fwd_bwd(degrad_patch, clean_patch, two_streams=ops.lib.records is None)
-
-    def _replay_parts(self) -> torch.Tensor:
-        """The parts' graphs side by side on the parts' streams, then the sum of the part gradients and losses."""
-        from . import ops
-
-        main = torch.cuda.current_stream(self._sx.device)
-        ready = torch.cuda.Event()
-        ready.record(main)
-        for g, st in zip(self._graph, self._streams):
-            st.wait_event(ready)
-            with torch.cuda.stream(st):
-                g.replay()
-            done = torch.cuda.Event()
-            done.record(st)
-            main.wait_event(done)
-        for i in range(1, len(self._graph)):
-            ops.add_(self.opt.grad, self._grads[i])
-        total = torch.empty_like(self._part_losses[0][0])
-        ops.copy_flat(self._part_losses[0][0].detach(), total)
-        for loss, _ in self._part_losses[1:]:
-            ops.add_(total, loss.detach())
-        return total
 
     def static_inputs(self):
         """The captured graph's own input buffers (degraded, clean) once a graph exists: a loader that writes its batch
