@@ -130,6 +130,30 @@ def test_weight_gradient_with_the_tall_operand_private_to_its_wave(b, cin, cout,
     assert torch.equal(got, again)
 
 
+@pytest.mark.parametrize("b,cin,cout,h,w,ln", [(2, 96, 510, 16, 16, False), (2, 96, 510, 32, 32, True), (3, 48, 254, 8, 16, False),
+                                               (2, 96, 288, 16, 16, True), (2, 96, 479, 8, 12, False), (5, 127, 48, 8, 8, False)])
+def test_grouped_row_loads_of_the_x_private_kernel_change_no_bit(b, cin, cout, h, w, ln):
+    """gemm_ntx.hip, knob 38: a row's four 16-byte loads of a step issued back to back (1: two-row-block kernels, the
+    default; 2: all) instead of half a step apart (0) - same products in the same order, so the results are bit-identical."""
+    from promptir_amd import _lib, ops
+
+    L = _lib.lib
+    xd, dyd = rnd("x", b, cin, h, w).to(DEV), rnd("dy", b, cout, h, w).to(DEV)
+    like = torch.empty(cout, cin, 1, 1, device=DEV)
+    gd, bd = (rnd("g", cin) + 1.5).to(DEV), rnd("b", cin).to(DEV)
+    _, mean, rstd = ops.layernorm_forward(xd, gd, bd)
+    outs = []
+    try:
+        assert L.pir_tune_set(25, 1) == 0
+        for mode in (0, 1, 2):
+            assert L.pir_tune_set(38, mode) == 0
+            outs.append((ops.conv1x1_wgrad_ln(dyd, xd, mean, rstd, gd, bd, like) if ln else ops.conv1x1_wgrad(dyd, xd, like)).clone())
+    finally:
+        L.pir_tune_set(25, -1)
+        L.pir_tune_set(38, 1)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 @pytest.mark.parametrize("b,cin,cout,h,w", [(2, 510, 192, 32, 32), (1, 127, 48, 16, 16), (2, 255, 96, 64, 64), (1, 1021, 384, 16, 16),
                                             (2, 90, 300, 8, 16), (1, 3, 48, 16, 16)])
 def test_k_tail_never_multiplies_what_lies_behind_the_operand(b, cin, cout, h, w):
