@@ -155,6 +155,11 @@ typedef struct {
 } pir_gemm_nt_t;
 size_t pir_gemm_nt_ws_floats(int M1, int M2, int N, int O, int BR);
 int pir_gemm_nt(const pir_gemm_nt_t* args, pir_stream_t stream);
+/* The same split-K product without its second stage: args->ws[s][o][i][j], s < *splits (host int, written at launch), keeps
+ * the partial sums and G is not written.  For the consumers that add the slices themselves in the reduction's order -
+ * pir_mdta_softmax_fwd_parts (q k^T, net/model.py:129) and pir_mdta_softmax_bwd_parts (dattn = dout v^T, adjoint of :133)
+ * - so that no reduction launch stands between the product and the softmax.  M1 >= M2, no shift. */
+int pir_gemm_nt_partials(const pir_gemm_nt_t* args, int* splits, pir_stream_t stream);
 /* n <= 4 products in ONE launch: the 1x1 weight gradients of one TransformerBlock (net/model.py:88,92,111,113) at the
  * 32^2 / 16^2 levels, where each alone has too few output tiles for the chip and splits its pixel axis 40 - 160 ways.
  * Every problem is a pir_gemm_nt_t of its own (O1 = O2 = 1, own ws); problems the grouped kernel does not serve run one
@@ -267,6 +272,11 @@ int pir_row_sumsq(const float* x, long x_bs, float* out, int B, int C, int HW, p
  * order: pir_row_sumsq gives nparts = 1, pir_dwconv3x3_sumsq one slice per row band). */
 int pir_mdta_softmax_fwd(const float* gram, const float* sumsq, int nparts, const float* temperature,
                          float* attn, int B, int heads, int c, pir_stream_t stream);
+/* ... reading the gram matrix as `splits` split-K partial slices (pir_gemm_nt_partials; [splits][B][h][c][c]), summed in
+ * the order of the stand-alone reduction (bit-identical); also writes the gram matrix ([B][h][c][c]) the backward reads */
+int pir_mdta_softmax_fwd_parts(const float* gram_parts, int splits, const float* sumsq, int nparts,
+                               const float* temperature, float* gram, float* attn, int B, int heads, int c,
+                               pir_stream_t stream);
 /* Backward through softmax, temperature and the two normalisations.
  * In: dattn, attn, gram, sumsq, temperature.  Out: dgram ([B][h][c][c], already divided by the
  * norms), alpha_q / alpha_k ([B][C]) such that
@@ -276,6 +286,11 @@ int pir_mdta_softmax_bwd(const float* dattn, const float* attn, const float* gra
                          int nparts, const float* temperature, float* dgram,
                          float* alpha_q, float* alpha_k, float* dtemp_partial,
                          int B, int heads, int c, pir_stream_t stream);
+/* ... reading dattn as `splits` split-K partial slices (pir_gemm_nt_partials), never materialised */
+int pir_mdta_softmax_bwd_parts(const float* dattn_parts, int splits, const float* attn, const float* gram,
+                               const float* sumsq, int nparts, const float* temperature, float* dgram,
+                               float* alpha_q, float* alpha_k, float* dtemp_partial,
+                               int B, int heads, int c, pir_stream_t stream);
 
 /* dq and dk of the MDTA backward from ONE pass over q and k (round 3):
  *   dq[b,h] = dgram[b,h] k[b,h] + alpha_q * q[b,h],   dk[b,h] = dgram[b,h]^T q[b,h] + alpha_k * k[b,h]

@@ -65,6 +65,7 @@ SIGNATURES = {
     "pir_conv3x3": (I, [P, L, L, L, I, P, L, P, L, P, L, I, I, I, I, I, S]),
     "pir_gemm_nt_ws_floats": (Z, [I, I, I, I, I]),
     "pir_gemm_nt": (I, [C.POINTER(GemmNT), S]),
+    "pir_gemm_nt_partials": (I, [C.POINTER(GemmNT), C.POINTER(C.c_int), S]),
     "pir_gemm_nt_group": (I, [C.POINTER(GemmNT), I, S]),
     "pir_gemm_nt_ws_needed": (Z, [C.POINTER(GemmNT)]),
     "pir_gemm_nt_group_ws_needed": (Z, [C.POINTER(GemmNT), I, I]),
@@ -90,6 +91,8 @@ SIGNATURES = {
     "pir_row_sumsq": (I, [P, L, P, I, I, I, S]),
     "pir_mdta_softmax_fwd": (I, [P, P, I, P, P, I, I, I, S]),
     "pir_mdta_softmax_bwd": (I, [P, P, P, P, I, P, P, P, P, P, I, I, I, S]),
+    "pir_mdta_softmax_fwd_parts": (I, [P, I, P, I, P, P, P, I, I, I, S]),
+    "pir_mdta_softmax_bwd_parts": (I, [P, I, P, P, P, I, P, P, P, P, P, I, I, I, S]),
     "pir_dwconv3x3_sumsq_floats": (Z, [I, I, I]),
     "pir_dwconv3x3_sumsq": (I, [P, L, P, P, L, P, Z, I, C.POINTER(C.c_int), I, I, I, I, S]),
     "pir_pixel_unshuffle2": (I, [P, L, P, L, I, I, I, I, S]),

@@ -873,7 +873,7 @@ void launch_nt_cfg(const NTParams& p, dim3 grid, bool vec4, hipStream_t s) {
 }
 
 // shared launcher of pir_gemm_nt and pir_conv3x3_wgrad: tile plan, split-K kernel, deterministic reduction
-int launch_nt(NTParams& p, size_t ws_floats, int tap_sign, long g_st, hipStream_t s) {
+int launch_nt(NTParams& p, size_t ws_floats, int tap_sign, long g_st, hipStream_t s, int* partials_only = nullptr) {
   pir_gemm_nt_t& g = p.g;
   const int O = g.O1 * g.O2;
   auto al = [](const float* q, long s1, long s2, long sr, long ld) {
@@ -939,6 +939,7 @@ int launch_nt(NTParams& p, size_t ws_floats, int tap_sign, long g_st, hipStream_
   }
   int st = pir_launch_status();
   if (st) return st;
+  if (partials_only) { *partials_only = pl.splits; return PIR_OK; }   // the consumer sums the slices itself (pir_split_sum)
   return pir_nt_reduce_submit(g.ws, pl.splits, O, g.M1, g.M2, g.G, g.g_so, g.g_si, g.g_sj, g_st, g.alpha, g.accumulate, s);
 }
 
@@ -1101,6 +1102,18 @@ extern "C" int pir_gemm_nt(const pir_gemm_nt_t* a, pir_stream_t stream) {
   pir_gemm_nt_t& g = p.g;
   nt_orient(g);   // G^T[j][i] = sum_n Y[j][n] X[i][n]: the output strides are free, so the larger extent goes on M1 (tile rows)
   return launch_nt(p, a->ws_floats, 0, 0L, (hipStream_t)stream);
+}
+
+// The split-K product WITHOUT its second stage: ws[s][o][i][j], s < *splits, holds the partial sums (alpha, accumulate and
+// the output strides are the consumer's business; `G` is not touched).  For consumers that read the partials themselves
+// in the reduction's order (pir_mdta_softmax_fwd_parts / _bwd_parts).  M1 >= M2 (no operand swap), no tap shift.
+extern "C" int pir_gemm_nt_partials(const pir_gemm_nt_t* a, int* splits, pir_stream_t stream) {
+  PIR_CHECK_ARG(a && splits && a->X && a->Y && a->ws);
+  PIR_CHECK_ARG(a->M1 > 0 && a->M2 > 0 && a->M1 >= a->M2 && a->N > 0 && a->O1 > 0 && a->O2 > 0 && a->BR > 0 && a->H == 0);
+  PIR_CHECK_ARG(a->O1 * a->O2 <= 65535);
+  NTParams p;
+  p.g = *a;
+  return launch_nt(p, a->ws_floats, 0, 0L, (hipStream_t)stream, splits);
 }
 
 // Up to four split-K products in ONE launch (the 1x1 weight gradients of a transformer block at the 32^2 / 16^2 levels,

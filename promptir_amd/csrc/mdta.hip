@@ -21,10 +21,15 @@ __device__ __forceinline__ float sum_parts(const float* __restrict__ p, int npar
 // (norm partials -> row -> exp -> store), so the rows of a map are spread over gridDim.y workgroups instead of being
 // walked six deep by one (10.7 -> ~5 us per launch at c = 96; B * heads is only 16 workgroups at the 128^2 level);
 // a row (c <= 256 columns) is loaded once into registers, the column norms once per wave.
+// PARTS: `gram` still holds the split-K partial sums of q k^T (`splits` slices, `pstride` floats apart): the kernel sums
+// them in the reduction's own order (pir_split_sum), writes the gram matrix the backward needs to `gram_out` and goes on -
+// the reduction launch between the product and the softmax is gone.
+template <bool PARTS>
 __global__ __launch_bounds__(1024) void mdta_softmax_fwd_kernel(const float* __restrict__ gram,
                                                                 const float* __restrict__ sumsq,
                                                                 const float* __restrict__ temperature,
-                                                                float* __restrict__ attn, int heads, int c, int nparts) {
+                                                                float* __restrict__ attn, int heads, int c, int nparts,
+                                                                float* __restrict__ gram_out, long pstride, int splits) {
   constexpr int MAXJ = 4;
   const int bh = blockIdx.x, b = bh / heads, h = bh % heads, C = heads * c;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -46,7 +51,16 @@ __global__ __launch_bounds__(1024) void mdta_softmax_fwd_kernel(const float* __r
 #pragma unroll
     for (int u = 0; u < MAXJ; ++u) {
       const int j = lane + 64 * u;
-      sv[u] = j < c ? G[i * c + j] * inv_q * inv_k[u] * t : -INFINITY;
+      float gij = 0.f;
+      if (j < c) {
+        if constexpr (PARTS) {
+          gij = pir_split_sum(gram, pstride, splits, (long)bh * c * c + i * c + j);
+          gram_out[(long)bh * c * c + i * c + j] = gij;
+        } else {
+          gij = G[i * c + j];
+        }
+      }
+      sv[u] = j < c ? gij * inv_q * inv_k[u] * t : -INFINITY;
       m = fmaxf(m, sv[u]);
     }
     m = pir_wave_max(m);
@@ -68,12 +82,13 @@ __global__ __launch_bounds__(1024) void mdta_softmax_fwd_kernel(const float* __r
 
 // Backward through softmax, temperature and both L2 normalisations (see include/promptir_hip.h).
 // MAXJ: 64-column groups per lane (c <= 64 * MAXJ); ROWS: rows of a wave whose loads are in flight together.
-template <int MAXJ, int ROWS>
+// PARTS: `dattn` holds split-K partial sums (see the forward kernel); dattn itself is never written.
+template <int MAXJ, int ROWS, bool PARTS = false>
 __global__ __launch_bounds__(1024) void mdta_softmax_bwd_kernel(
     const float* __restrict__ dattn, const float* __restrict__ attn, const float* __restrict__ gram,
     const float* __restrict__ sumsq, const float* __restrict__ temperature, float* __restrict__ dgram,
     float* __restrict__ alpha_q, float* __restrict__ alpha_k, float* __restrict__ dtemp_partial, int heads, int c,
-    int nparts) {
+    int nparts, long pstride, int splits) {
   __shared__ float colred[16][64 * MAXJ];
   __shared__ float red[16];
   const int bh = blockIdx.x, b = bh / heads, h = bh % heads, C = heads * c;
@@ -107,7 +122,8 @@ __global__ __launch_bounds__(1024) void mdta_softmax_bwd_kernel(
       for (int u = 0; u < MAXJ; ++u) {
         const int j = lane + 64 * u;
         av[r][u] = j < c ? A[ic * c + j] : 0.f;
-        dav[r][u] = j < c ? dA[ic * c + j] : 0.f;
+        if constexpr (PARTS) dav[r][u] = j < c ? pir_split_sum(dattn, pstride, splits, (long)bh * c * c + ic * c + j) : 0.f;
+        else dav[r][u] = j < c ? dA[ic * c + j] : 0.f;
         gv[r][u] = j < c ? G[ic * c + j] : 0.f;
         dot[r] += dav[r][u] * av[r][u];
       }
@@ -156,8 +172,17 @@ __global__ __launch_bounds__(1024) void mdta_softmax_bwd_kernel(
 extern "C" int pir_mdta_softmax_fwd(const float* gram, const float* sumsq, int nparts, const float* temperature,
                                     float* attn, int B, int heads, int c, pir_stream_t stream) {
   PIR_CHECK_ARG(gram && sumsq && temperature && attn && B > 0 && heads > 0 && c > 0 && c <= 256 && nparts > 0);
-  hipLaunchKernelGGL(mdta_softmax_fwd_kernel, dim3((unsigned)(B * heads), (unsigned)pir_cdiv(c, 16)), dim3(1024), 0,
-                     (hipStream_t)stream, gram, sumsq, temperature, attn, heads, c, nparts);
+  hipLaunchKernelGGL(mdta_softmax_fwd_kernel<false>, dim3((unsigned)(B * heads), (unsigned)pir_cdiv(c, 16)), dim3(1024), 0,
+                     (hipStream_t)stream, gram, sumsq, temperature, attn, heads, c, nparts, (float*)nullptr, 0L, 0);
+  return pir_launch_status();
+}
+
+extern "C" int pir_mdta_softmax_fwd_parts(const float* gram_parts, int splits, const float* sumsq, int nparts,
+                                          const float* temperature, float* gram, float* attn, int B, int heads, int c,
+                                          pir_stream_t stream) {
+  PIR_CHECK_ARG(gram_parts && splits > 0 && gram && sumsq && temperature && attn && B > 0 && heads > 0 && c > 0 && c <= 256 && nparts > 0);
+  hipLaunchKernelGGL(mdta_softmax_fwd_kernel<true>, dim3((unsigned)(B * heads), (unsigned)pir_cdiv(c, 16)), dim3(1024), 0,
+                     (hipStream_t)stream, gram_parts, sumsq, temperature, attn, heads, c, nparts, gram, (long)B * heads * c * c, splits);
   return pir_launch_status();
 }
 
@@ -168,7 +193,21 @@ extern "C" int pir_mdta_softmax_bwd(const float* dattn, const float* attn, const
   PIR_CHECK_ARG(dattn && attn && gram && sumsq && temperature && dgram && alpha_q && alpha_k && dtemp_partial);
   PIR_CHECK_ARG(B > 0 && heads > 0 && c > 0 && c <= 256 && nparts > 0);
 #define PIR_SMB(MJ, RW) hipLaunchKernelGGL((mdta_softmax_bwd_kernel<MJ, RW>), dim3((unsigned)(B * heads)), dim3(1024), 0, \
-      (hipStream_t)stream, dattn, attn, gram, sumsq, temperature, dgram, alpha_q, alpha_k, dtemp_partial, heads, c, nparts)
+      (hipStream_t)stream, dattn, attn, gram, sumsq, temperature, dgram, alpha_q, alpha_k, dtemp_partial, heads, c, nparts, 0L, 0)
+  if (c <= 64) PIR_SMB(1, 4); else if (c <= 128) PIR_SMB(2, 6); else PIR_SMB(4, 3);
+#undef PIR_SMB
+  return pir_launch_status();
+}
+
+extern "C" int pir_mdta_softmax_bwd_parts(const float* dattn_parts, int splits, const float* attn, const float* gram,
+                                          const float* sumsq, int nparts, const float* temperature, float* dgram,
+                                          float* alpha_q, float* alpha_k, float* dtemp_partial,
+                                          int B, int heads, int c, pir_stream_t stream) {
+  PIR_CHECK_ARG(dattn_parts && splits > 0 && attn && gram && sumsq && temperature && dgram && alpha_q && alpha_k && dtemp_partial);
+  PIR_CHECK_ARG(B > 0 && heads > 0 && c > 0 && c <= 256 && nparts > 0);
+  const long ps = (long)B * heads * c * c;
+#define PIR_SMB(MJ, RW) hipLaunchKernelGGL((mdta_softmax_bwd_kernel<MJ, RW, true>), dim3((unsigned)(B * heads)), dim3(1024), 0, \
+      (hipStream_t)stream, dattn_parts, attn, gram, sumsq, temperature, dgram, alpha_q, alpha_k, dtemp_partial, heads, c, nparts, ps, splits)
   if (c <= 64) PIR_SMB(1, 4); else if (c <= 128) PIR_SMB(2, 6); else PIR_SMB(4, 3);
 #undef PIR_SMB
   return pir_launch_status();

@@ -40,6 +40,57 @@ __device__ __forceinline__ int pir_xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
+// Sum of the S split-K partials of element e (partials `stride` floats apart) in EXACTLY the order of the stand-alone
+// second stage (reduce_batch.hip: reduce_wide_body with 4 groups below 64 splits, 16 from there on: every group walks
+// its splits with four accumulators, the groups are added in order): a consumer that reads the partials itself - the
+// MDTA softmax kernels do, for the gram matrix and for dattn - gets the very bits the reduction launch would have written.
+__device__ __forceinline__ float pir_split_sum(const float* __restrict__ p, long stride, int S, long e) {
+  if (S < 64) {
+    // four groups x four accumulators = sixteen independent chains: the loads of a round are all in flight together (walked
+    // group by group the sum is a chain of S / 4 dependent load latencies - as long as the launch it replaces).  Every chain
+    // sees its elements in the order of reduce_wide_body<4>: full rounds while k + 12 < S, the rest of a group into s0.
+    float s[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) s[g][a] = 0.f;
+    int kk[4] = {0, 1, 2, 3};
+    for (int base = 0; base + 12 < S; base += 16) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int k = base + g;
+        if (k + 12 < S) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) s[g][a] += p[(long)(k + 4 * a) * stride + e];
+          kk[g] = k + 16;
+        }
+      }
+    }
+    float tot = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      for (int k = kk[g]; k < S; k += 4) s[g][0] += p[(long)k * stride + e];
+      tot += (s[g][0] + s[g][1]) + (s[g][2] + s[g][3]);
+    }
+    return tot;
+  }
+  const int GR = 16;
+  float tot = 0.f;
+  for (int grp = 0; grp < GR; ++grp) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = grp;
+    for (; k + 3 * GR < S; k += 4 * GR) {
+      s0 += p[(long)k * stride + e];
+      s1 += p[(long)(k + GR) * stride + e];
+      s2 += p[(long)(k + 2 * GR) * stride + e];
+      s3 += p[(long)(k + 3 * GR) * stride + e];
+    }
+    for (; k < S; k += GR) s0 += p[(long)k * stride + e];
+    tot += (s0 + s1) + (s2 + s3);
+  }
+  return tot;
+}
+
 // Division of a small index by a runtime divisor without the ~30-instruction integer-divide sequence:
 // magic = floor(2^32 / d) + 1 (host side, pir_magic), exact for n * d < 2^32.
 // d == 1 has no 32-bit magic: encoded as 0 and handled by the select.

@@ -47,7 +47,7 @@ class _TimedLib:
             o = g.O1 * g.O2
             shared = g.a_s1 == 0 and g.a_s2 == 0
             return 4.0 * o * (g.K * g.N + g.M * g.N * (2 if g.R else 1)) + 4.0 * g.M * g.K * (1 if shared else o)
-        if name == "pir_gemm_nt":
+        if name in ("pir_gemm_nt", "pir_gemm_nt_partials"):
             g = args[0]._obj
             return 4.0 * g.O1 * g.O2 * g.BR * (g.M1 + g.M2) * g.N
         if name == "pir_gemm_nt_group":
@@ -94,7 +94,7 @@ class _TimedLib:
         if name == "pir_gemm_nn":
             g = args[0]._obj
             return 2.0 * g.M * g.K * g.N * g.O1 * g.O2
-        if name == "pir_gemm_nt":
+        if name in ("pir_gemm_nt", "pir_gemm_nt_partials"):
             g = args[0]._obj
             return 2.0 * g.M1 * g.M2 * g.N * g.O1 * g.O2 * g.BR
         if name == "pir_gemm_nt_group":
@@ -181,7 +181,7 @@ def effective_switches() -> dict:
     """Everything that can change which kernels the product path runs: the module switches below, every PIR_*
     environment variable and every tuning knob set in this process.  bench.py prints it with its line."""
     mod = {k: globals()[k] for k in ("USE_X3", "MDTA_FOLD", "LN_FOLD", "LN_TRAIN", "DGRAD_LN", "MDTA_DQK", "MDTA_FOLD_MIN_HW",
-                                      "USE_SIDE_STREAM", "CAT_INPLACE", "SHUFFLE_FOLD", "NT_GROUP") if k in globals()}
+                                      "USE_SIDE_STREAM", "SOFTMAX_PARTS", "CAT_INPLACE", "SHUFFLE_FOLD", "NT_GROUP") if k in globals()}
     return {"switches": mod, "env": {k: v for k, v in sorted(_os.environ.items()) if k.startswith("PIR_")},
             "knobs_set": {str(k): v for k, v in sorted(_KNOBS_SET.items())}}
 
@@ -475,6 +475,41 @@ def gemm_nt(X: torch.Tensor, x_off: int, x_str: Tuple[int, int, int], ldx: int,
     check(lib.pir_gemm_nt(C.byref(g), _stream()), "pir_gemm_nt")
 
 
+def gemm_nt_partials(X, x_off, x_str, ldx, Y, y_off, y_str, ldy, M1: int, M2: int, N: int, O1: int, O2: int, BR: int):
+    """The split-K product of `gemm_nt` WITHOUT its second stage (pir_gemm_nt_partials): returns (workspace, splits) - the
+    slices ws[s][o][i][j] stay in the stream's reused workspace, valid until the next call on this stream takes it; the
+    consumer launched next reads and adds them (MDTA softmax kernels)."""
+    g = _lib.GemmNT()
+    g.X, g.x_s1, g.x_s2, g.x_sr, g.ldx = X.data_ptr() + 4 * x_off, x_str[0], x_str[1], x_str[2], ldx
+    g.Y, g.y_s1, g.y_s2, g.y_sr, g.ldy = Y.data_ptr() + 4 * y_off, y_str[0], y_str[1], y_str[2], ldy
+    g.G, g.g_so, g.g_si, g.g_sj = None, 0, 0, 0
+    g.M1, g.M2, g.N, g.O1, g.O2, g.BR = M1, M2, N, O1, O2, BR
+    st = _stream()
+    ws = _WS_main(lib.pir_gemm_nt_ws_floats(M1, M2, N, O1 * O2, BR), X.device, st)
+    g.ws, g.ws_floats = ws.data_ptr(), ws.numel()
+    g.alpha, g.accumulate = 1.0, 0
+    splits = C.c_int(0)
+    check(lib.pir_gemm_nt_partials(C.byref(g), C.byref(splits), st), "pir_gemm_nt_partials")
+    return ws, splits.value
+
+
+def _WS_main(nfloats: int, device: torch.device, st: int) -> torch.Tensor:
+    """The stream's one reused scratch buffer (never an arena piece)."""
+    key = (device.index, "main", st)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nfloats:
+        if buf is not None:
+            _WS_RETIRED.append(buf)
+        buf = torch.empty(max(int(nfloats), 1 << 16), dtype=torch.float32, device=device)
+        _WS[key] = buf
+    return buf
+
+
+# gram / dattn split-K slices summed by the softmax kernels instead of by a reduction launch (-140 launches per step,
+# bit-identical).  OPT-IN: measured +0.4 ms at batch 32, +0.25 ms at batch 8, +0.08 ms per batch-8 inference on one box
+# (three interleaved pairs): the reduction launch spreads its loads over hundreds of workgroups, the softmax kernel adds
+# the slices inside the block's dependent chain.
+SOFTMAX_PARTS = _os.environ.get("PIR_SOFTMAX_PARTS", "0") != "0"
 NT_GROUP = _os.environ.get("PIR_NT_GROUP", "1") != "0"     # low-resolution weight gradients of a block in one launch
 NT_GROUP_MAX_HW = int(_os.environ.get("PIR_NT_GROUP_MAX_HW", "1024"))
 
@@ -981,10 +1016,16 @@ def mdta_attn_forward(qkv: torch.Tensor, temperature: torch.Tensor, heads: int, 
         check(lib.pir_row_sumsq(qkv.data_ptr(), bs, sumsq.data_ptr(), b, 2 * c_all, hw, _stream()), "pir_row_sumsq")
     nparts = sumsq.shape[1]
     gram = torch.empty((b, heads, c, c), dtype=torch.float32, device=dev)
+    attn = torch.empty_like(gram)
+    if SOFTMAX_PARTS and USE_X3:     # the softmax kernel adds the split-K slices of q k^T itself: no reduction launch
+        with tagged("mdta"):
+            ws, splits = gemm_nt_partials(qkv, 0, (bs, c * hw, 0), hw, qkv, c_all * hw, (bs, c * hw, 0), hw, c, c, hw, b, heads, 1)
+        check(lib.pir_mdta_softmax_fwd_parts(ws.data_ptr(), splits, sumsq.data_ptr(), nparts, temperature.data_ptr(),
+                                             gram.data_ptr(), attn.data_ptr(), b, heads, c, _stream()), "pir_mdta_softmax_fwd_parts")
+        return attn, gram, sumsq
     with tagged("mdta"):
         gemm_nt(qkv, 0, (bs, c * hw, 0), hw, qkv, c_all * hw, (bs, c * hw, 0), hw, gram, 0, (c * c, c, 1),
                 c, c, hw, b, heads, 1)
-    attn = torch.empty_like(gram)
     check(lib.pir_mdta_softmax_fwd(gram.data_ptr(), sumsq.data_ptr(), nparts, temperature.data_ptr(), attn.data_ptr(),
                                    b, heads, c, _stream()), "pir_mdta_softmax_fwd")
     return attn, gram, sumsq
@@ -993,7 +1034,8 @@ def mdta_attn_forward(qkv: torch.Tensor, temperature: torch.Tensor, heads: int, 
 @_tag_calls("mdta")
 def mdta_attn_backward(dattn, qkv, temperature, heads, attn, gram, sumsq, dqkv, dtemp_out=None):
     """From dattn to dq, dk (written into the q / k thirds of `dqkv`) and dtemperature: backward through softmax,
-    temperature and the two L2 normalisations (net/model.py:127-131)."""
+    temperature and the two L2 normalisations (net/model.py:127-131).  `dattn`: the tensor, or (workspace, splits) - the
+    split-K slices of dout v^T, which the softmax kernel then adds itself (gemm_nt_partials)."""
     b, c3, h, w = qkv.shape
     c_all = c3 // 3
     c = c_all // heads
@@ -1004,9 +1046,15 @@ def mdta_attn_backward(dattn, qkv, temperature, heads, attn, gram, sumsq, dqkv, 
     alpha_q = torch.empty((b, c_all), dtype=torch.float32, device=dev)
     alpha_k = torch.empty_like(alpha_q)
     dtemp_part = torch.empty((b, heads), dtype=torch.float32, device=dev)
-    check(lib.pir_mdta_softmax_bwd(dattn.data_ptr(), attn.data_ptr(), gram.data_ptr(), sumsq.data_ptr(), sumsq.shape[1],
-                                   temperature.data_ptr(), dgram.data_ptr(), alpha_q.data_ptr(), alpha_k.data_ptr(),
-                                   dtemp_part.data_ptr(), b, heads, c, _stream()), "pir_mdta_softmax_bwd")
+    if isinstance(dattn, tuple):
+        check(lib.pir_mdta_softmax_bwd_parts(dattn[0].data_ptr(), dattn[1], attn.data_ptr(), gram.data_ptr(), sumsq.data_ptr(),
+                                             sumsq.shape[1], temperature.data_ptr(), dgram.data_ptr(), alpha_q.data_ptr(),
+                                             alpha_k.data_ptr(), dtemp_part.data_ptr(), b, heads, c, _stream()),
+              "pir_mdta_softmax_bwd_parts")
+    else:
+        check(lib.pir_mdta_softmax_bwd(dattn.data_ptr(), attn.data_ptr(), gram.data_ptr(), sumsq.data_ptr(), sumsq.shape[1],
+                                       temperature.data_ptr(), dgram.data_ptr(), alpha_q.data_ptr(), alpha_k.data_ptr(),
+                                       dtemp_part.data_ptr(), b, heads, c, _stream()), "pir_mdta_softmax_bwd")
     # dq = dG k + alpha_q * q and dk = dG^T q + alpha_k * k from ONE pass over q and k where the fused kernel serves the
     # shape (48 rows per head, whole 32-pixel blocks); 1000 = not served, nothing launched
     if MDTA_DQK:
@@ -1058,6 +1106,13 @@ def mdta_core_backward(dout, qkv, temperature, heads, attn, gram, sumsq, dtemp_o
     dqkv = torch.empty((b, c3, h, w), dtype=torch.float32, device=dev)
     qbs = c3 * hw
     # dA = dout v^T
+    if SOFTMAX_PARTS and USE_X3:     # its split-K slices go straight to the softmax backward: no reduction launch, no dattn
+        dattn = gemm_nt_partials(dout, 0, (dbs, c * hw, 0), hw, qkv, 2 * c_all * hw, (bs, c * hw, 0), hw, c, c, hw, b, heads, 1)
+        dtemp = mdta_attn_backward(dattn, qkv, temperature, heads, attn, gram, sumsq, dqkv, dtemp_out)   # (reads the slices next)
+        # dv = A^T dout :  A'(m=j, k=i) = attn[i*c + j]
+        gemm_nn(attn, (heads * c * c, c * c), 1, c, dout, 0, (dbs, c * hw), hw,
+                dqkv, 2 * c_all * hw, (qbs, c * hw), hw, c, c, hw, b, heads)
+        return dqkv, dtemp
     dattn = torch.empty_like(attn)
     with immediate_reductions():     # the softmax backward reads dattn next
         gemm_nt(dout, 0, (dbs, c * hw, 0), hw, qkv, 2 * c_all * hw, (bs, c * hw, 0), hw, dattn, 0, (c * c, c, 1),

@@ -584,6 +584,27 @@ def test_mdta_core(heads, c, hw):
     close(dtemp, tr.grad, rtol=1e-4)
 
 
+@pytest.mark.parametrize("heads,c,hw,b", [(1, 48, 16384, 4), (2, 48, 4096, 3), (4, 48, 1024, 16), (8, 48, 256, 16), (1, 96, 4096, 2),
+                                           (2, 96, 64, 2), (4, 40, 128, 2), (2, 48, 99, 2)])
+def test_softmax_kernels_add_the_split_k_slices_in_the_reductions_order(heads, c, hw, b, monkeypatch):
+    """q k^T and dout v^T leave their split-K slices in the workspace (pir_gemm_nt_partials) and the MDTA softmax kernels add
+    them in the order of the stand-alone second stage (pir_split_sum): attn, the saved gram matrix, dq, dk, dv and
+    dtemperature are bit-identical to the path with the two reduction launches; split counts from 2 to 40."""
+    from promptir_amd import ops
+
+    C = heads * c
+    h, w = (hw // 8, 8) if hw % 8 == 0 else (9, 11)
+    qkv, temp, dout = rnd("qkv", b, 3 * C, h, w).to(DEV), (rnd("t", heads, 1, 1) * 0.5 + 1.0).to(DEV), rnd("do", b, C, h, w).to(DEV)
+    res = []
+    for parts in (False, True):
+        monkeypatch.setattr(ops, "SOFTMAX_PARTS", parts)
+        og, attn, gram, sumsq = ops.mdta_core_forward(qkv, temp, heads)
+        dqkv, dtemp = ops.mdta_core_backward(dout, qkv, temp, heads, attn, gram, sumsq)
+        res.append([t.clone() for t in (og, attn, gram, dqkv, dtemp)])
+    for a, bb in zip(*res):
+        assert torch.equal(a, bb)
+
+
 def test_gemm_nt_determinism_and_linearity():
     """Size-independent properties at a BASELINE-sized contraction (batch 8, 128x128 pixels)."""
     from promptir_amd import ops
