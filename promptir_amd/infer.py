@@ -24,13 +24,14 @@ class GraphedForward:
         # as in the trainer: from eight images on the batch runs as two halves on two streams inside the graph (the small
         # kernels of one half fill the gaps of the other)
         self.part_streams = int(os.environ.get("PIR_INFER_STREAMS", "2")) if part_streams is None else part_streams
+        self.min_part = max(1, int(os.environ.get("PIR_INFER_MIN_PART", "4")))    # images per part stream at least
         self._streams = None
 
     def _forward_parts(self, sx: torch.Tensor, sy: torch.Tensor = None):
         from . import ops
 
         b = sx.shape[0]
-        n = min(self.part_streams, max(1, b // 4))
+        n = min(self.part_streams, max(1, b // self.min_part))
         if n <= 1:
             return self.net(sx)
         if self._streams is None or len(self._streams) < n:
