@@ -278,6 +278,8 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
   pir_nn_epilogue<TM, TN>(acc, g, Y, o1, o2, m0, n0, wm, wn, lane);
 }
 
+int g_x3_fill32 = 45;  // knob 43: 32 x 128 tiles when the 96 x 128 plan would give fewer workgroups than this percentage of the CUs (0: never);
+                       // tools/deep_ab.py at part batches of 1 / 4: 0.66 - 0.86 of the 96 x 128 tile's time up to 69 % fill, 1.16 at 75 %
 int g_x3_breg = -1;   // knob 18: activations stay in registers in the one-wave-per-column-block tile (96 x 128): -1 automatic
                       // (planes of <= 4096 pixels: -2..-9 %, bit-identical; neutral to worse at 128^2), 0 never, 1 always
 
@@ -455,6 +457,7 @@ int g_x3_narrow96 = 4;   // pir_tune_set knob 5: 96 x 128 instead of 96 x 256 be
 int pir_nn_x3_tune(int knob, int value) {
   if (knob == 5) { g_x3_narrow96 = value; return PIR_OK; }
   if (knob == 18) { g_x3_breg = value; return PIR_OK; }
+  if (knob == 43) { g_x3_fill32 = value; return PIR_OK; }
   if (knob == 29) { g_x3_conv_fill = value; return PIR_OK; }
   return PIR_EINVAL;
 }
@@ -484,6 +487,7 @@ int pir_nn_x3_plan(const pir_gemm_nn_t* a, int cfg) {
       case 2: return 3214;
       case 3: return 2222;
       case 7: return 3114;   // 96 x 128
+      case 8: return 1114;   // 32 x 128
       default: return 1222;
     }
   }
@@ -495,6 +499,10 @@ int pir_nn_x3_plan(const pir_gemm_nn_t* a, int cfg) {
   // Low-resolution levels (32^2, 16^2: long k loops, few columns): the three-workgroups-per-CU tiles win by 6-12 %
   // over 96 x 256 / 64 x 128 (tools/cfg_ab.py over every level, profiles/r02_gemm_nn_tile_sweep.txt): 96 x 128 unless
   // 128-row tiles waste fewer rows (M = 510, 1020, 1021, 2042); also the 64^2 level's qkv (M = 288)
+  // Underfilled launches (fewer 96 x 128 workgroups than g_x3_fill32 percent of the CUs: the 16^2 / 32^2 levels at part batches
+  // of 1 - 4 images): 32-row tiles - three times the workgroups, a third of the MFMAs in every k-step's serial chain
+  if (g.A3 && g_x3_fill32 > 0 && M >= 64 && g.N <= 4096 &&
+      pir_cdiv(M, 96) * pir_cdiv(g.N, 128) * batch * 100 < (long)g_x3_fill32 * PIR_NUM_CU) return 1114;
   if (g.A3 && M >= 192 && g.N <= 1024) return pad128 < pad96 ? 2222 : 3114;
   if (g.A3 && M >= 192 && g.N <= 4096 && g.K <= 128 && pad96 < pad128) return 3114;
   // Short k loops on long pixel rows (forward / input gradient of the 1x1 convolutions at the 128^2 and 64^2 levels,
@@ -520,6 +528,7 @@ int pir_nn_x3_launch(const pir_gemm_nn_t* a, int cfg, hipStream_t s) {
     case 3214: return launch_cfg<3, 2, 1, 4>(g, s);
     case 2222: return launch_cfg<2, 2, 2, 2>(g, s);
     case 3114: return launch_cfg<3, 1, 1, 4>(g, s);
+    case 1114: return launch_cfg<1, 1, 1, 4>(g, s);
     default: return launch_cfg<1, 2, 2, 2>(g, s);
   }
 }

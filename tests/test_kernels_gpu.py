@@ -130,6 +130,32 @@ def test_weight_gradient_with_the_tall_operand_private_to_its_wave(b, cin, cout,
     assert torch.equal(got, again)
 
 
+@pytest.mark.parametrize("b,cin,cout,h,w", [(2, 192, 1020, 16, 16), (1, 1021, 384, 16, 16), (3, 48, 96, 8, 16), (2, 130, 200, 8, 8),
+                                            (1, 510, 192, 32, 32), (4, 384, 2042, 16, 16), (1, 2042, 384, 16, 16), (1, 96, 70, 8, 16)])
+def test_narrow_tiles_of_underfilled_launches_change_no_bit(b, cin, cout, h, w):
+    """gemm_x3.hip, knob 43: where the 96 x 128 plan leaves most CUs without a workgroup (the 16^2 / 32^2 levels at part
+    batches of 1 - 4 images) the 1x1 convolutions run 32 x 128 tiles - three times the workgroups, a third of the MFMAs in
+    each k-step's serial chain.  Every output element is the same sum in the same order: forward, forward + residual and
+    input gradient are bit-identical with the rule off (0), at its default and forced on (100)."""
+    from promptir_amd import _lib, ops
+
+    L = _lib.lib
+    x, wt, res = rnd("x", b, cin, h, w).to(DEV), rnd("w", cout, cin, 1, 1).to(DEV), rnd("r", b, cout, h, w).to(DEV)
+    dy = rnd("dy", b, cout, h, w).to(DEV)
+    outs = []
+    try:
+        for mode in (0, 45, 100):
+            assert L.pir_tune_set(43, mode) == 0
+            outs.append([ops.conv1x1_forward(x, wt).clone(), ops.conv1x1_forward(x, wt, residual=res).clone(),
+                         ops.conv1x1_dgrad(dy, wt).clone()])
+    finally:
+        L.pir_tune_set(43, 45)
+    for other in outs[1:]:
+        for a, bb in zip(outs[0], other):
+            assert torch.equal(a, bb)
+    close(outs[0][0], F.conv2d(x.cpu(), wt.cpu()), rtol=2e-5)
+
+
 @pytest.mark.parametrize("b,cin,cout,h,w,ln", [(2, 96, 510, 16, 16, False), (2, 96, 510, 32, 32, True), (3, 48, 254, 8, 16, False),
                                                (2, 96, 288, 16, 16, True), (2, 96, 479, 8, 12, False), (5, 127, 48, 8, 8, False)])
 def test_grouped_row_loads_of_the_x_private_kernel_change_no_bit(b, cin, cout, h, w, ln):
