@@ -339,9 +339,13 @@ void gemm_nn_cst_kernel(CstArgs p) {
 }
 
 int g_cst_mode = -1;   // knob 26: -1 automatic, 0 never, 1 whenever the shape is served
-int g_cst_split = 0;      // knob 32: 192-channel fused LayerNorm backward with the rows of a block split between two waves
+int g_cst_split = -1;     // knob 32 (-1: automatic - where the launch has at most one column block per CU: batch-8 step -0.45 ms, round 4): 192-channel fused LayerNorm backward with the rows of a block split between two waves
                           // (isolated 0.78 of the one-wave variant's time, no effect inside the two-stream step: off)
 int g_cst_ln_maxc = 192;   // knob 27: most channels the fused LayerNorm backward serves (A/B of the 192-channel variant)
+
+inline bool cst_split_on(const pir_gemm_nn_t& g) {
+  return g_cst_split < 0 ? (long)g.O1 * (g.N / 32) <= PIR_NUM_CU : g_cst_split != 0;
+}
 
 bool cst_plan(const pir_gemm_nn_t& g, CstArgs& a, int& grid, int& pk, bool lnb = false) {
   if (g_cst_mode == 0 && !lnb) return false;
@@ -352,7 +356,7 @@ bool cst_plan(const pir_gemm_nn_t& g, CstArgs& a, int& grid, int& pk, bool lnb =
   if (g.a3_kp != kp || ks < (g.M == 48 ? 8 : 12)) return false;
   // 96 rows: eight waves, panels of 8 or 6 k-steps; 192 rows: four waves (all registers of a SIMD to one wave), panels of 4;
   // fused LayerNorm backward at 192 rows: the rows of a block split between two waves, two blocks per round and workgroup
-  const int nw = g.M == 96 || g.M == 48 ? 8 : (lnb && g_cst_split ? 2 : 4);
+  const int nw = g.M == 96 || g.M == 48 ? 8 : (lnb && cst_split_on(g) ? 2 : 4);
   pk = g.M == 192 ? (ks % 4 == 0 ? 4 : 0) : g.M == 48 ? (ks % 8 == 0 ? 8 : ks == 9 ? 9 : 0) : ks % 8 == 0 ? 8 : ks % 6 == 0 ? 6 : 0;
   if (!pk) return false;
   // plain 192-row products (32^2 level) gain nothing over the tiled kernel (tools/cst_ab.py: 0.99-1.05 at batch 32, half
@@ -429,7 +433,7 @@ extern "C" int pir_conv1x1_dgrad_ln_bwd(const float* dy, long dy_bs, const void*
   if (C == 48 && pk == 9) hipLaunchKernelGGL((gemm_nn_cst_kernel<2, 9, 8, true, 48>), dim3((unsigned)grid), dim3(512), 0, s, a);
   else if (C == 48 && pk == 8) hipLaunchKernelGGL((gemm_nn_cst_kernel<2, 8, 8, true, 48>), dim3((unsigned)grid), dim3(512), 0, s, a);
   else if (C == 48) return 1000;
-  else if (C == 192 && g_cst_split) hipLaunchKernelGGL((gemm_nn_cst_kernel<3, 4, 4, true, 192, 2>), dim3((unsigned)grid), dim3(256), 0, s, a);
+  else if (C == 192 && cst_split_on(g)) hipLaunchKernelGGL((gemm_nn_cst_kernel<3, 4, 4, true, 192, 2>), dim3((unsigned)grid), dim3(256), 0, s, a);
   else if (C == 192) hipLaunchKernelGGL((gemm_nn_cst_kernel<6, 4, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
   else if (pk == 8) hipLaunchKernelGGL((gemm_nn_cst_kernel<3, 8, 8, true>), dim3((unsigned)grid), dim3(512), 0, s, a);
   else hipLaunchKernelGGL((gemm_nn_cst_kernel<3, 6, 8, true>), dim3((unsigned)grid), dim3(512), 0, s, a);
