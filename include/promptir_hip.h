@@ -182,6 +182,14 @@ int pir_split_bf16x3_taps(const float* W, int M, int K, long st, long sm, long s
                           pir_stream_t stream);   /* out holds 9 * pir_split_bf16x3_bytes(M, K) bytes */
 int pir_conv3x3_x3(const void* A3, int a3_kp, const float* X, long x_bs, float* Y, long y_bs,
                    const float* R, long r_bs, int B, int M, int K, int H, int W, pir_stream_t stream);
+/* The same convolution with a scratch buffer of pir_conv3x3_x3_ws_floats(...) floats (0: none needed): a launch that would leave
+ * most of the chip idle behind a long stage loop (the up / down-sampling and prompt convolutions at the 16^2 / 32^2 levels,
+ * net/model.py:164,174,223: 48 - 96 workgroups walking 72 - 432 stages) is cut into slices of its stages that run side by
+ * side; a deterministic second stage adds the partial sums in order.  Same results to fp32 rounding. */
+size_t pir_conv3x3_x3_ws_floats(int B, int M, int K, int H, int W);
+int pir_conv3x3_x3_ws(const void* A3, int a3_kp, const float* X, long x_bs, float* Y, long y_bs,
+                      const float* R, long r_bs, int B, int M, int K, int H, int W,
+                      float* ws, size_t ws_floats, pir_stream_t stream);
 
 /* Every pre-split weight of a model refreshed by ONE launch (after an optimiser step): descs (device memory)
  * lists the tensors, blocks (device memory, nblocks x {descriptor index, 4096-element chunk index}) the work.

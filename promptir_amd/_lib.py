@@ -72,6 +72,8 @@ SIGNATURES = {
     "pir_split_bf16x3_batch": (I, [P, P, I, S]),
     "pir_split_bf16x3_taps": (I, [P, I, I, L, L, L, I, P, S]),
     "pir_conv3x3_x3": (I, [P, I, P, L, P, L, P, L, I, I, I, I, I, S]),
+    "pir_conv3x3_x3_ws": (I, [P, I, P, L, P, L, P, L, I, I, I, I, I, P, Z, S]),
+    "pir_conv3x3_x3_ws_floats": (Z, [I, I, I, I, I]),
     "pir_conv3x3_wgrad_ws_floats": (Z, [I, I, I, I, I]),
     "pir_conv3x3_wgrad": (I, [P, L, P, L, P, I, I, I, I, I, P, Z, I, S]),
     "pir_layernorm_fwd": (I, [P, L, P, P, P, L, P, P, I, I, I, S]),

@@ -25,6 +25,10 @@ struct RowsArgs {
   pir_gemm_nn_t g;
   int H, W, wshift;   // W = 1 << wshift
   int ksteps;         // a3_kp / 16
+  // split over the stages (row shift, k-step): gridDim.z workgroups share an output tile, workgroup z multiplies stages
+  // [z per, (z + 1) per) and writes its partial sums to `Y + z * part_stride` (the residual goes into slice 0); the caller
+  // adds the slices in order (pir_reduce_partials).  For launches that leave most CUs idle behind k loops of 72 - 432 stages.
+  int splits; long part_stride;
 };
 
 template <int TM, int TN, int WM, int WN>
@@ -51,8 +55,9 @@ void conv3x3_rows_kernel(RowsArgs p) {
   const int wg = pir_xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (wg % tiles_m) * BM, n0 = (wg / tiles_m) * BN;
   const int o1 = blockIdx.y;
+  const int zs = blockIdx.z;
   const float* __restrict__ X = g.X + o1 * g.x_s1;
-  float* __restrict__ Y = g.Y + o1 * g.y_s1;
+  float* __restrict__ Y = g.Y + o1 * g.y_s1 + zs * p.part_stride;
   const int h = lane >> 5, r = lane & 31;
   const int qk = ((r >> 4) << 2) | (r & 3), qj = (r >> 2) & 3;   // lane -> (pixel quad, row in the quad group): gemm_res.hip
   const int ldx4 = (int)g.ldx * 4;
@@ -165,16 +170,20 @@ void conv3x3_rows_kernel(RowsArgs p) {
   };
 
   // stages s = (dy + 1) * ksteps + ks; the next stage's loads fly while this one is multiplied
-  const int stages = 3 * p.ksteps;
+  const int stages_all = 3 * p.ksteps;
+  const int per = (stages_all + p.splits - 1) / p.splits;
+  const int s_lo = zs * per < stages_all ? zs * per : stages_all, s_hi = s_lo + per < stages_all ? s_lo + per : stages_all;
+  const int stages = s_hi - s_lo;                         // this workgroup's share (all of them without a split)
   f32x4 raw[BPW][2];
   bf16x8 areg[NLA];
-  int dyi = 0, ks = 0;
-  auto advance = [&](int s) {      // (dyi, ks) -> the stage after s (behind the last stage: its own again, unused)
+  int dyi = s_lo / p.ksteps, ks = s_lo - dyi * p.ksteps;
+  if (dyi > 2) { dyi = 2; ks = 0; }                       // (an empty share: loads stay in range, nothing is multiplied)
+  auto advance = [&](int s) {      // (dyi, ks) -> the stage after local stage s (behind the last one: its own again, unused)
     if (s + 1 >= stages) return;
     if (++ks == p.ksteps) { ks = 0; ++dyi; }
   };
-  load_b(-1, 0, raw);
-  load_a(0, 0, areg);
+  load_b(dyi - 1, ks, raw);
+  load_a(dyi, ks, areg);
   __syncthreads();                                        // the zero fill is complete
   if constexpr (DB) {
     stash_b(raw, 0);
@@ -206,6 +215,12 @@ void conv3x3_rows_kernel(RowsArgs p) {
       __syncthreads();
     }
   }
+  if (zs != 0) {                                          // the residual belongs to slice 0 only
+    pir_gemm_nn_t gz = g;
+    gz.R = nullptr;
+    pir_nn_epilogue<TM, TN>(acc, gz, Y, o1, 0, m0, n0, wm, wn, lane);
+    return;
+  }
   pir_nn_epilogue<TM, TN>(acc, g, Y, o1, 0, m0, n0, wm, wn, lane);
 }
 
@@ -215,7 +230,7 @@ template <int TM, int TN, int WM, int WN>
 int rows_launch(const RowsArgs& a, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   if (BN % a.W != 0 || a.g.N % BN != 0) return 1000;
-  dim3 grid((unsigned)(pir_cdiv(a.g.M, BM) * (a.g.N / BN)), (unsigned)a.g.O1), block(WM * WN * 64);
+  dim3 grid((unsigned)(pir_cdiv(a.g.M, BM) * (a.g.N / BN)), (unsigned)a.g.O1, (unsigned)a.splits), block(WM * WN * 64);
   hipLaunchKernelGGL((conv3x3_rows_kernel<TM, TN, WM, WN>), grid, block, 0, s, a);
   return pir_launch_status();
 }
@@ -229,12 +244,23 @@ int pir_conv_rows_tune(int knob, int value) {
 }
 
 // tile = the plan code of pir_conv3x3_x3's own choice (TM TN WM WN digits); 1000: shape not served (nothing launched)
-int pir_conv_rows_launch(const pir_gemm_nn_t* g, int H, int W, int tile, hipStream_t s) {
+// does the whole-row kernel serve the shape (the split over the stages exists in that kernel only)?
+bool pir_conv_rows_serves(const pir_gemm_nn_t* g, int W, int tile) {
+  if (!g_rows_mode) return false;
+  if (W < 16 || W > 256 || (W & (W - 1)) != 0 || g->O2 != 1) return false;
+  if ((reinterpret_cast<uintptr_t>(g->X) & 15) || g->x_s1 % 4 || g->ldx % 4) return false;
+  const int bn = (tile / 100 % 10) * (tile % 10) * 32;
+  return bn % W == 0 && g->N % bn == 0;
+}
+
+// splits > 1: g->Y is the slice buffer ([splits][B][M][N], y_s1 = M N); part_stride = B M N
+int pir_conv_rows_launch(const pir_gemm_nn_t* g, int H, int W, int tile, hipStream_t s, int splits, long part_stride) {
   if (!g_rows_mode) return 1000;
   if (W < 16 || W > 256 || (W & (W - 1)) != 0 || g->O2 != 1) return 1000;
   if ((reinterpret_cast<uintptr_t>(g->X) & 15) || g->x_s1 % 4 || g->ldx % 4) return 1000;
   RowsArgs a;
   a.g = *g; a.H = H; a.W = W; a.ksteps = g->a3_kp / 16;
+  a.splits = splits; a.part_stride = part_stride;
   a.wshift = 0;
   while ((1 << a.wshift) < W) ++a.wshift;
   switch (tile) {

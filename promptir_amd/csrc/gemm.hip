@@ -964,7 +964,7 @@ extern "C" int pir_tune_set(int knob, int value) {
     case 2: g_nt_splits = value; return PIR_OK;
     case 3: g_nn_x3 = value; return PIR_OK;
     case 4: g_nt_x3 = value; return PIR_OK;
-    case 5: case 18: case 29: case 43: return pir_nn_x3_tune(knob, value);
+    case 5: case 18: case 29: case 43: case 44: return pir_nn_x3_tune(knob, value);
     case 6: case 7: return pir_gdfn_wave_tune(knob, value);
     case 8: case 9: case 10: return pir_stencil_wave_tune(knob, value);
     case 13: case 16: return pir_ln_tune(knob, value);

@@ -120,7 +120,8 @@ int pir_nn_res_tune(int knob, int value);
 int pir_nn_res_tune2(int knob, int value);
 
 // dense 3x3 convolution with whole image rows per tile (conv_rows.hip): 1000 = shape not served
-int pir_conv_rows_launch(const pir_gemm_nn_t* g, int H, int W, int tile, hipStream_t stream);
+int pir_conv_rows_launch(const pir_gemm_nn_t* g, int H, int W, int tile, hipStream_t stream, int splits = 1, long part_stride = 0);
+bool pir_conv_rows_serves(const pir_gemm_nn_t* g, int W, int tile);
 int pir_conv_rows_tune(int knob, int value);
 
 // C-stationary persistent kernel for few rows against a long k (gemm_cst.hip): 1000 = shape not served

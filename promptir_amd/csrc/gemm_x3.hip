@@ -390,8 +390,52 @@ extern "C" int pir_split_bf16x3_taps(const float* W, int M, int K, long st, long
   return pir_launch_status();
 }
 
-extern "C" int pir_conv3x3_x3(const void* A3, int a3_kp, const float* X, long x_bs, float* Y, long y_bs, const float* R,
-                              long r_bs, int B, int M, int K, int H, int W, pir_stream_t stream) {
+int g_x3_conv_split = 1;   // knob 44: split of the underfilled dense 3x3 convolutions over their stages (0: never)
+
+// tile of the dense convolution (rows = output channels, often few)
+static int conv_tile(int M, int N, int B) {
+  const long pad96 = pir_cdiv(M, 96) * 96, pad128 = pir_cdiv(M, 128) * 128;
+  const long blocks128 = pir_cdiv(M, 128) * pir_cdiv(N, 128) * B;
+  if (M <= 32) return 1214;
+  if (M <= 64) return 2214;
+  if (pad96 <= pad128 && N >= 256) {
+    // the low-resolution convolutions (16^2, 32^2 planes, a part batch of images) give 96 x 256 tiles only 64-128 workgroups
+    // with k loops of 200-430 steps: narrower tiles until the chip is about filled (tools/conv3x3_bench.py)
+    const long wg256 = pir_cdiv(M, 96) * pir_cdiv(N, 256) * B, wg128 = pir_cdiv(M, 96) * pir_cdiv(N, 128) * B;
+    if (g_x3_conv_fill && wg256 < PIR_NUM_CU) return wg128 >= 3L * PIR_NUM_CU / 4 ? 3114 : 1222;
+    return 3214;
+  }
+  if (blocks128 < 2L * PIR_NUM_CU && pir_cdiv(M, 64) * 64 <= pad128) return 1222;
+  return 2222;
+}
+
+// Slices the stage loop (3 row shifts x a3_kp / 16 k-steps) of an underfilled launch is cut into: as many as fill two
+// workgroups per CU, at least 12 stages each; 1 = no split.
+static int conv_splits(int tile, int M, int N, int B, int a3_kp) {
+  if (!g_x3_conv_split) return 1;
+  const int bm = (tile / 1000) * (tile / 10 % 10) * 32, bn = (tile / 100 % 10) * (tile % 10) * 32;
+  const long wgs = pir_cdiv(M, bm) * pir_cdiv(N, bn) * B;
+  const int stages = 3 * (a3_kp / 16);
+  long s = 2L * PIR_NUM_CU / wgs;
+  if (s > stages / 12) s = stages / 12;
+  if (s > 8) s = 8;
+  // (two slices of an about-filled launch measured worse: up3_2 at 16 images 106 -> 137 us)
+  return s < 3 ? 1 : (int)s;
+}
+
+// workspace floats pir_conv3x3_x3_ws wants for this call (0: it would not split; any buffer, or none, will do)
+extern "C" size_t pir_conv3x3_x3_ws_floats(int B, int M, int K, int H, int W) {
+  if (B <= 0 || M <= 0 || K <= 0 || H <= 0 || W <= 0) return 0;
+  const int tile = conv_tile(M, H * W, B);
+  const int sp = conv_splits(tile, M, H * W, B, (int)(pir_cdiv(K, 16) * 16));
+  return sp > 1 ? (size_t)sp * B * M * H * W : 0;
+}
+
+int pir_reduce_partials_now(const float* parts, long stride, int S, float alpha, int accumulate, float* out, long count,
+                            pir_stream_t stream);   // reduce_batch.hip: launched at once, never queued
+
+static int conv3x3_x3_impl(const void* A3, int a3_kp, const float* X, long x_bs, float* Y, long y_bs, const float* R,
+                           long r_bs, int B, int M, int K, int H, int W, float* ws, size_t ws_floats, pir_stream_t stream) {
   PIR_CHECK_ARG(A3 && X && Y && B > 0 && M > 0 && K > 0 && H > 0 && W > 0 && B <= 65535);
   PIR_CHECK_ARG(a3_kp == (int)(pir_cdiv(K, 16) * 16));
   PIR_CHECK_ARG((long)(M > K ? M : K) * H * W < (1L << 28) && 54L * M * a3_kp < (1L << 31));
@@ -409,20 +453,20 @@ extern "C" int pir_conv3x3_x3(const void* A3, int a3_kp, const float* X, long x_
   cv.H = H; cv.W = W; cv.ksteps = a3_kp / 16;
   cv.magic_ks = pir_magic((unsigned)cv.ksteps); cv.magic_w = pir_magic((unsigned)W);
   hipStream_t s = (hipStream_t)stream;
-  // tile choice as for gemm_nn (rows = output channels, often few)
-  int tile;
-  const long pad96 = pir_cdiv(M, 96) * 96, pad128 = pir_cdiv(M, 128) * 128;
-  const long blocks128 = pir_cdiv(M, 128) * pir_cdiv(g.N, 128) * B;
-  if (M <= 32) tile = 1214;
-  else if (M <= 64) tile = 2214;
-  else if (pad96 <= pad128 && g.N >= 256) {
-    // the low-resolution convolutions (16^2, 32^2 planes, a part batch of images) give 96 x 256 tiles only 64-128 workgroups
-    // with k loops of 200-430 steps: narrower tiles until the chip is about filled (tools/conv3x3_bench.py)
-    const long wg256 = pir_cdiv(M, 96) * pir_cdiv(g.N, 256) * B, wg128 = pir_cdiv(M, 96) * pir_cdiv(g.N, 128) * B;
-    tile = 3214;
-    if (g_x3_conv_fill && wg256 < PIR_NUM_CU) tile = wg128 >= 3L * PIR_NUM_CU / 4 ? 3114 : 1222;
-  } else if (blocks128 < 2L * PIR_NUM_CU && pir_cdiv(M, 64) * 64 <= pad128) tile = 1222;
-  else tile = 2222;
+  const int tile = conv_tile(M, g.N, B);
+  // Underfilled launch behind a long stage loop (up4_3: 48 - 96 workgroups walking 72 - 432 stages, 92 - 175 us at any batch
+  // size): the stages are cut into slices that run side by side, each writes its partial sums (the residual rides in slice
+  // 0) and the deterministic second stage adds them in order.  Needs a contiguous output and the whole-row kernel.
+  const int sp = conv_splits(tile, M, g.N, B, a3_kp);
+  const long out_floats = (long)B * M * g.N;
+  if (sp > 1 && ws && (size_t)sp * out_floats <= ws_floats && y_bs == (long)M * g.N && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 &&
+      pir_conv_rows_serves(&g, W, tile)) {
+    pir_gemm_nn_t gs = g;
+    gs.Y = ws; gs.y_s1 = (long)M * g.N;
+    int st = pir_conv_rows_launch(&gs, H, W, tile, s, sp, out_floats);
+    if (st) return st;
+    return pir_reduce_partials_now(ws, out_floats, sp, 1.f, 0, Y, out_floats, stream);
+  }
   {   // whole image rows per tile, activations loaded once per row shift (conv_rows.hip) where the shape allows
     const int st = pir_conv_rows_launch(&g, H, W, tile, s);
     if (st != 1000) return st;
@@ -435,6 +479,19 @@ extern "C" int pir_conv3x3_x3(const void* A3, int a3_kp, const float* X, long x_
     case 1222: return launch_cfg<1, 2, 2, 2>(g, s, &cv);
     default: return launch_cfg<2, 2, 2, 2>(g, s, &cv);
   }
+}
+
+extern "C" int pir_conv3x3_x3(const void* A3, int a3_kp, const float* X, long x_bs, float* Y, long y_bs, const float* R,
+                              long r_bs, int B, int M, int K, int H, int W, pir_stream_t stream) {
+  return conv3x3_x3_impl(A3, a3_kp, X, x_bs, Y, y_bs, R, r_bs, B, M, K, H, W, nullptr, 0, stream);
+}
+
+// The same convolution with a scratch buffer (pir_conv3x3_x3_ws_floats): launches that would leave most of the chip idle
+// behind a long stage loop are split over their stages (results agree with the unsplit launch to fp32 rounding: another
+// grouping of the same sum; deterministic).
+extern "C" int pir_conv3x3_x3_ws(const void* A3, int a3_kp, const float* X, long x_bs, float* Y, long y_bs, const float* R,
+                                 long r_bs, int B, int M, int K, int H, int W, float* ws, size_t ws_floats, pir_stream_t stream) {
+  return conv3x3_x3_impl(A3, a3_kp, X, x_bs, Y, y_bs, R, r_bs, B, M, K, H, W, ws, ws_floats, stream);
 }
 
 extern "C" size_t pir_split_bf16x3_bytes(int M, int K) {
@@ -459,6 +516,7 @@ int pir_nn_x3_tune(int knob, int value) {
   if (knob == 18) { g_x3_breg = value; return PIR_OK; }
   if (knob == 43) { g_x3_fill32 = value; return PIR_OK; }
   if (knob == 29) { g_x3_conv_fill = value; return PIR_OK; }
+  if (knob == 44) { g_x3_conv_split = value; return PIR_OK; }
   return PIR_EINVAL;
 }
 

@@ -217,6 +217,17 @@ int pir_reduce_partials_to2(const float* parts, long stride, int S, float alpha,
   return submit(d, (hipStream_t)stream);
 }
 
+// never queued: the next kernel on the stream reads `out` (split dense convolutions, gemm_x3.hip)
+int pir_reduce_partials_now(const float* parts, long stride, int S, float alpha, int accumulate, float* out, long count,
+                            pir_stream_t stream) {
+  PIR_CHECK_ARG(parts && out && S > 0 && count > 0);
+  ReduceDesc d{};
+  d.parts = parts; d.stride = stride; d.count = count; d.out = out; d.out2 = nullptr; d.split = 0;
+  d.S = S; d.alpha = alpha; d.accumulate = accumulate;
+  d.kind = (S >= 256 && count <= 4096) ? RB_NARROW : (S >= 64 ? RB_PLAIN16 : RB_PLAIN4);
+  return launch_one(d, (hipStream_t)stream);
+}
+
 extern "C" int pir_reduce_partials(const float* parts, long stride, int S, float alpha, int accumulate,
                                    float* out, long count, pir_stream_t stream) {
   return pir_reduce_partials_to2(parts, stride, S, alpha, accumulate, out, nullptr, 0, count, stream);

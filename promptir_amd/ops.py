@@ -64,7 +64,7 @@ class _TimedLib:
         if name == "pir_conv3x3_wgrad":            # dy and x read once
             b, cout, cin, h, w = args[5:10]
             return 4.0 * b * h * w * (cout + cin)
-        if name in ("pir_conv3x3", "pir_conv3x3_x3"):   # x read, y written (+ residual)
+        if name in ("pir_conv3x3", "pir_conv3x3_x3", "pir_conv3x3_x3_ws"):   # x read, y written (+ residual)
             b, m, k, h, w = args[11:16] if name == "pir_conv3x3" else args[8:13]
             return 4.0 * b * h * w * (k + m)
         # ---- depthwise stencils (HBM roofline): algorithmic planes x 4 bytes, SURVEY 8(d) / DESIGN 4
@@ -111,7 +111,7 @@ class _TimedLib:
         if name == "pir_conv3x3":
             b, m, k, h, w = args[11:16]
             return 2.0 * 9 * m * k * h * w * b
-        if name == "pir_conv3x3_x3":
+        if name in ("pir_conv3x3_x3", "pir_conv3x3_x3_ws"):
             b, m, k, h, w = args[8:13]
             return 2.0 * 9 * m * k * h * w * b
         if name == "pir_conv3x3_wgrad":
@@ -772,6 +772,13 @@ def conv1x1_wgrad(dy: torch.Tensor, x: torch.Tensor, like: torch.Tensor, out: Op
     return dw
 
 
+def _conv3x3_ws(b: int, m: int, k: int, h: int, wd: int, device) -> Optional[torch.Tensor]:
+    """Scratch for a dense 3x3 convolution the library would split over its stages (underfilled launches at the low-resolution
+    levels: pir_conv3x3_x3_ws_floats > 0); a slot of its own - the slices are consumed by the reduction launched with them."""
+    need = lib.pir_conv3x3_x3_ws_floats(b, m, k, h, wd)
+    return workspace(need, device, slot="conv3x3") if need else None
+
+
 def conv3x3_forward(x: torch.Tensor, w: torch.Tensor, residual: Optional[torch.Tensor] = None,
                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
     x = _planes(x)
@@ -784,8 +791,9 @@ def conv3x3_forward(x: torch.Tensor, w: torch.Tensor, residual: Optional[torch.T
     r_bs = _bs(residual) if residual is not None else 0
     if USE_X3:
         a3, kp = _split_weight(w, dgrad=False, taps=True)
-        check(lib.pir_conv3x3_x3(a3.data_ptr(), kp, x.data_ptr(), _bs(x), out.data_ptr(), _bs(out), _p(residual), r_bs,
-                                 b, cout, cin, h, wd, _stream()), "pir_conv3x3_x3")
+        ws = _conv3x3_ws(b, cout, cin, h, wd, x.device)
+        check(lib.pir_conv3x3_x3_ws(a3.data_ptr(), kp, x.data_ptr(), _bs(x), out.data_ptr(), _bs(out), _p(residual), r_bs,
+                                    b, cout, cin, h, wd, _p(ws), ws.numel() if ws is not None else 0, _stream()), "pir_conv3x3_x3_ws")
     else:
         check(lib.pir_conv3x3(w.data_ptr(), 1, cin * 9, 9, 0, x.data_ptr(), _bs(x), out.data_ptr(), _bs(out),
                               _p(residual), r_bs, b, cout, cin, h, wd, _stream()), "pir_conv3x3")
@@ -799,8 +807,9 @@ def conv3x3_dgrad(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     out = torch.empty((b, cin, h, wd), dtype=torch.float32, device=dy.device)
     if USE_X3:
         a3, kp = _split_weight(w, dgrad=True, taps=True)
-        check(lib.pir_conv3x3_x3(a3.data_ptr(), kp, dy.data_ptr(), _bs(dy), out.data_ptr(), _bs(out), None, 0,
-                                 b, cin, cout, h, wd, _stream()), "pir_conv3x3_x3(dgrad)")
+        ws = _conv3x3_ws(b, cin, cout, h, wd, dy.device)
+        check(lib.pir_conv3x3_x3_ws(a3.data_ptr(), kp, dy.data_ptr(), _bs(dy), out.data_ptr(), _bs(out), None, 0,
+                                    b, cin, cout, h, wd, _p(ws), ws.numel() if ws is not None else 0, _stream()), "pir_conv3x3_x3_ws(dgrad)")
     else:
         # A(tap, m=cin, k=cout) = w[k][m][8-tap]
         check(lib.pir_conv3x3(w.data_ptr(), 1, 9, cin * 9, 1, dy.data_ptr(), _bs(dy), out.data_ptr(), _bs(out),

@@ -130,6 +130,40 @@ def test_weight_gradient_with_the_tall_operand_private_to_its_wave(b, cin, cout,
     assert torch.equal(got, again)
 
 
+@pytest.mark.parametrize("b,cin,cout,h,w", [(4, 384, 768, 16, 16), (1, 192, 384, 32, 32), (4, 320, 320, 16, 16), (2, 192, 96, 32, 32),
+                                            (1, 100, 70, 16, 32), (3, 64, 64, 64, 64)])
+def test_dense_convolutions_split_over_their_stages(b, cin, cout, h, w):
+    """gemm_x3.hip / conv_rows.hip, knob 44: underfilled dense 3x3 convolutions (up / down-sampling and prompt convolutions
+    at the 16^2 / 32^2 levels) are cut into slices of their (row shift, k-step) stages that run side by side; the slices'
+    partial sums are added in order by the deterministic second stage.  Forward (+ residual) and input gradient against
+    F.conv2d on the CPU and against the unsplit launch (another grouping of the same sum: fp32 rounding), and bit-stable
+    across launches; (3, 64, 64, 64, 64) is filled well enough not to be split."""
+    from promptir_amd import _lib, ops
+
+    L = _lib.lib
+    x, wt, res = rnd("x", b, cin, h, w), rnd("w", cout, cin, 3, 3) * 0.1, rnd("r", b, cout, h, w)
+    dy = rnd("dy", b, cout, h, w)
+    xr = x.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wt, padding=1)
+    ref.backward(dy)
+    xd, wd_, rd, dyd = x.to(DEV), wt.to(DEV), res.to(DEV), dy.to(DEV)
+    outs = []
+    try:
+        for mode in (0, 1, 1):
+            assert L.pir_tune_set(44, mode) == 0
+            outs.append([ops.conv3x3_forward(xd, wd_).clone(), ops.conv3x3_forward(xd, wd_, residual=rd).clone(),
+                         ops.conv3x3_dgrad(dyd, wd_).clone()])
+    finally:
+        L.pir_tune_set(44, 1)
+    for a, bb in zip(outs[1], outs[2]):
+        assert torch.equal(a, bb)
+    close(outs[1][0], ref.detach(), rtol=3e-5)
+    close(outs[1][1], ref.detach() + res, rtol=3e-5)
+    close(outs[1][2], xr.grad, rtol=3e-5)
+    for a, bb in zip(outs[0], outs[1]):
+        close(a, bb.cpu(), rtol=1e-5)
+
+
 @pytest.mark.parametrize("b,cin,cout,h,w", [(2, 192, 1020, 16, 16), (1, 1021, 384, 16, 16), (3, 48, 96, 8, 16), (2, 130, 200, 8, 8),
                                             (1, 510, 192, 32, 32), (4, 384, 2042, 16, 16), (1, 2042, 384, 16, 16), (1, 96, 70, 8, 16)])
 def test_narrow_tiles_of_underfilled_launches_change_no_bit(b, cin, cout, h, w):
