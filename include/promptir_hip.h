@@ -75,6 +75,12 @@ typedef struct {
   const void* A3; int a3_kp;
 } pir_gemm_nn_t;
 int pir_gemm_nn(const pir_gemm_nn_t* args, pir_stream_t stream);
+/* The same product with a scratch buffer of pir_gemm_nn_ws_floats(args) floats (0: none needed).  Where the launch would leave
+ * most CUs idle behind a long k loop (the 384-row 1x1 convolutions of the 16^2 level, net/model.py:88,92,111,113 at
+ * k = 1021 ... 2042) the k loop is cut into slices that run side by side and a deterministic second stage adds the partial
+ * sums in order: same result to fp32 rounding.  Needs pre-split weights (A3) and one contiguous output per image. */
+size_t pir_gemm_nn_ws_floats(const pir_gemm_nn_t* args);
+int pir_gemm_nn_ws(const pir_gemm_nn_t* args, float* ws, size_t ws_floats, pir_stream_t stream);
 /* y[b] = W LayerNorm_c(x[b]) for the no_grad forward (round 3): the channel LayerNorm (WithBias, net/model.py:60-63) is
  * applied as the activations are loaded by the persistent B-stationary kernel, so the normalised tensor of
  * `self.attn(self.norm1(x))` / `self.ffn(self.norm2(x))` (:192-196) is never written or read.  A3 = pir_split_bf16x3 of

@@ -59,6 +59,8 @@ SIGNATURES = {
     "pir_tune_set": (I, [I, I]),
     "pir_build_flags": (I, []),
     "pir_gemm_nn": (I, [C.POINTER(GemmNN), S]),
+    "pir_gemm_nn_ws": (I, [C.POINTER(GemmNN), P, Z, S]),
+    "pir_gemm_nn_ws_floats": (Z, [C.POINTER(GemmNN)]),
     "pir_gemm_nn_plan": (I, [C.POINTER(GemmNN)]),
     "pir_split_bf16x3_bytes": (Z, [I, I]),
     "pir_split_bf16x3": (I, [P, I, I, L, L, P, S]),

@@ -964,7 +964,7 @@ extern "C" int pir_tune_set(int knob, int value) {
     case 2: g_nt_splits = value; return PIR_OK;
     case 3: g_nn_x3 = value; return PIR_OK;
     case 4: g_nt_x3 = value; return PIR_OK;
-    case 5: case 18: case 29: case 43: case 44: return pir_nn_x3_tune(knob, value);
+    case 5: case 18: case 29: case 43: case 44: case 45: return pir_nn_x3_tune(knob, value);
     case 6: case 7: return pir_gdfn_wave_tune(knob, value);
     case 8: case 9: case 10: return pir_stencil_wave_tune(knob, value);
     case 13: case 16: return pir_ln_tune(knob, value);
@@ -994,7 +994,24 @@ extern "C" int pir_gemm_nn_plan(const pir_gemm_nn_t* a) {
   return pir_nn_x3_plan(a, g_nn_cfg);
 }
 
-extern "C" int pir_gemm_nn(const pir_gemm_nn_t* a, pir_stream_t stream) {
+int pir_reduce_partials_now(const float* parts, long stride, int S, float alpha, int accumulate, float* out, long count,
+                            pir_stream_t stream);   // reduce_batch.hip: launched at once, never queued
+
+// which kernel family serves the call without a split: 0 tiled bf16x3 (the only one that splits over k)
+static int nn_x3_tiled(const pir_gemm_nn_t* a) {
+  if (!pir_nn_x3_wanted(a, g_nn_x3)) return 0;
+  if (g_nn_cfg < 0 && (pir_nn_cst_serves(a) || pir_nn_res_kind(a))) return 0;
+  return 1;
+}
+
+// scratch floats pir_gemm_nn_ws wants for this call (0: it would not split over k)
+extern "C" size_t pir_gemm_nn_ws_floats(const pir_gemm_nn_t* a) {
+  if (!a || a->M <= 0 || a->K <= 0 || a->N <= 0 || a->O1 <= 0 || a->O2 <= 0 || !nn_x3_tiled(a)) return 0;
+  const int sp = pir_nn_x3_ksplit(a, g_nn_cfg);
+  return sp > 1 ? (size_t)sp * a->O1 * a->M * a->N : 0;
+}
+
+static int gemm_nn_impl(const pir_gemm_nn_t* a, float* ws, size_t ws_floats, pir_stream_t stream) {
   PIR_CHECK_ARG(a && a->A && a->X && a->Y);
   PIR_CHECK_ARG(a->M > 0 && a->K > 0 && a->N > 0 && a->O1 > 0 && a->O2 > 0);
   PIR_CHECK_ARG((long)a->O1 * a->O2 <= 65535);
@@ -1010,12 +1027,32 @@ extern "C" int pir_gemm_nn(const pir_gemm_nn_t* a, pir_stream_t stream) {
       st = pir_nn_res_launch(a, (hipStream_t)stream);
       if (st != 1000) return st;
     }
+    // Underfilled deep-k product (the 384-row products of the 16^2 level: 32 - 128 workgroups walking 64 - 128 k-steps): the k
+    // loop is cut into slices that run side by side; partial sums (residual and row scale in slice 0) go to the scratch
+    // buffer and the deterministic second stage adds them in order.
+    const int sp = ws ? pir_nn_x3_ksplit(a, g_nn_cfg) : 1;
+    const long out_floats = (long)a->O1 * a->M * a->N;
+    if (sp > 1 && (size_t)sp * out_floats <= ws_floats && (reinterpret_cast<uintptr_t>(ws) & 15) == 0) {
+      pir_gemm_nn_t gs = *a;
+      gs.Y = ws;
+      const int st = pir_nn_x3_launch(&gs, g_nn_cfg, (hipStream_t)stream, sp, out_floats);
+      if (st) return st;
+      return pir_reduce_partials_now(ws, out_floats, sp, 1.f, 0, a->Y, out_floats, stream);
+    }
     return pir_nn_x3_launch(a, g_nn_cfg, (hipStream_t)stream);
   }
   NNParams p;
   p.g = *a;
   p.taps = 1; p.flip = 0; p.H = 0; p.W = 0; p.a_st = 0;
   return launch_nn(p, (hipStream_t)stream);
+}
+
+extern "C" int pir_gemm_nn(const pir_gemm_nn_t* a, pir_stream_t stream) { return gemm_nn_impl(a, nullptr, 0, stream); }
+
+// pir_gemm_nn with a scratch buffer of pir_gemm_nn_ws_floats(a) floats: the same product, split over k where the launch would
+// leave most CUs idle behind a long k loop (same result to fp32 rounding: another grouping of the same sum; deterministic)
+extern "C" int pir_gemm_nn_ws(const pir_gemm_nn_t* a, float* ws, size_t ws_floats, pir_stream_t stream) {
+  return gemm_nn_impl(a, ws, ws_floats, stream);
 }
 
 extern "C" int pir_conv3x3(const float* A, long a_st, long a_sm, long a_sk, int flip,

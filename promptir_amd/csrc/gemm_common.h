@@ -109,7 +109,8 @@ __device__ __forceinline__ f32x16 pir_mfma_x3(const pir_bf16x8& ah, const pir_bf
 
 // bf16x3 split path (gemm_x3.hip): exact-fp32-class results from six bf16 MFMAs per product block.
 bool pir_nn_x3_wanted(const pir_gemm_nn_t* a, int knob);
-int pir_nn_x3_launch(const pir_gemm_nn_t* a, int cfg, hipStream_t stream);
+int pir_nn_x3_launch(const pir_gemm_nn_t* a, int cfg, hipStream_t stream, int ksplit = 1, long part_stride = 0);
+int pir_nn_x3_ksplit(const pir_gemm_nn_t* a, int cfg);
 int pir_nn_x3_plan(const pir_gemm_nn_t* a, int cfg);
 int pir_nn_x3_tune(int knob, int value);
 

@@ -37,7 +37,9 @@ __device__ __forceinline__ Frag3 split8(const float (&v)[8], bool ok) {
 }
 
 // dense 3x3 convolution as 9 x ceil(K/16) stages: stage it = (tap, k-step); the tap shifts the activation columns
-struct X3Conv { int H, W, ksteps; unsigned magic_ks, magic_w; };
+// (ksplit, part_stride: plain products only - gridDim.z workgroups share an output tile, workgroup z multiplies its share of
+// the k-steps and writes partial sums to Y + z * part_stride, the residual / row scale ride in slice 0; see pir_gemm_nn_ws)
+struct X3Conv { int H, W, ksteps; unsigned magic_ks, magic_w; int ksplit; long part_stride; };
 
 // A_PRE: A comes pre-split (pir_split_bf16x3): a fragment is three 16-byte loads, no conversion work.
 // CONV (needs A_PRE, weights from pir_split_bf16x3_taps): the k loop also runs over the nine taps.
@@ -60,12 +62,16 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
   const int o1 = blockIdx.y / g.O2, o2 = blockIdx.y % g.O2;
   const float* __restrict__ A = g.A + o1 * g.a_s1 + o2 * g.a_s2;
   const float* __restrict__ X = g.X + o1 * g.x_s1 + o2 * g.x_s2;
-  float* __restrict__ Y = g.Y + o1 * g.y_s1 + o2 * g.y_s2;
+  float* __restrict__ Y = g.Y + o1 * g.y_s1 + o2 * g.y_s2 + (CONV ? 0L : (long)blockIdx.z * cv.part_stride);
 
   constexpr int AF = 2 * BM, NA = (AF + T - 1) / T;   // 8-deep k fragments per stage
   constexpr int BF = 2 * BN, NB = (BF + T - 1) / T;
   struct Stage { float a[A_PRE ? 1 : NA][8]; bf16x8 a3[A_PRE ? NA : 1][3]; float b[NB][8]; };
-  const int iters = CONV ? 9 * cv.ksteps : (g.K + XK - 1) / XK;
+  const int iters_all = CONV ? 9 * cv.ksteps : (g.K + XK - 1) / XK;
+  // split over k: this workgroup's k-steps are it_base .. it_base + iters - 1 (the host gives every slice at least one)
+  const int ks_per = (!CONV && cv.ksplit > 1) ? (iters_all + cv.ksplit - 1) / cv.ksplit : iters_all;
+  const int it_base = (!CONV && cv.ksplit > 1) ? (int)blockIdx.z * ks_per : 0;
+  const int iters = iters_all - it_base < ks_per ? iters_all - it_base : ks_per;
 
   // fragment -> (row, k-group).  k-fast A (forward weights): the two k-groups of a row sit on adjacent lanes
   auto a_map = [&](int f, int& mm, int& kg) { if (A_MFAST) { mm = f % BM; kg = f / BM; } else { kg = f & 1; mm = f >> 1; } };
@@ -108,7 +114,7 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
   const int a3_part_bytes = (CONV ? 9 : 1) * g.M * g.a3_kp * 2, a3_step_bytes = g.M * 32, ldx4 = (int)g.ldx * 4;
 
   auto load = [&](int it_raw, Stage& st) {
-    const int it = it_raw < iters ? it_raw : iters - 1;
+    const int it = it_base + (it_raw < iters ? it_raw : iters - 1);
     int tap = 0, ks = it;
     if (CONV) { tap = pir_fastdiv(it, cv.magic_ks); ks = it - tap * cv.ksteps; }
     const int k0 = ks * XK, klast = g.K - 1 - k0;
@@ -275,6 +281,12 @@ void gemm_nn_x3_kernel(pir_gemm_nn_t g, X3Conv cv) {
   }
   if (it < iters) compute(0);
 
+  if (!CONV && blockIdx.z != 0) {      // residual and row scale belong to slice 0
+    pir_gemm_nn_t gz = g;
+    gz.R = nullptr; gz.rowscale = nullptr;
+    pir_nn_epilogue<TM, TN>(acc, gz, Y, o1, o2, m0, n0, wm, wn, lane);
+    return;
+  }
   pir_nn_epilogue<TM, TN>(acc, g, Y, o1, o2, m0, n0, wm, wn, lane);
 }
 
@@ -286,11 +298,11 @@ int g_x3_breg = -1;   // knob 18: activations stay in registers in the one-wave-
 int g_x3_conv_fill = 1;   // pir_tune_set knob 29: narrower dense-3x3 tiles when 96 x 256 leaves the chip underfilled
 
 template <int TM, int TN, int WM, int WN>
-int launch_cfg(const pir_gemm_nn_t& g, hipStream_t s, const X3Conv* conv = nullptr) {
+int launch_cfg(const pir_gemm_nn_t& g, hipStream_t s, const X3Conv* conv = nullptr, int ksplit = 1, long part_stride = 0) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const long tiles = pir_cdiv(g.M, BM) * pir_cdiv(g.N, BN);
-  dim3 grid((unsigned)tiles, (unsigned)(g.O1 * g.O2)), block(WM * WN * 64);
-  X3Conv cv = {0, 0, 0, 0u, 0u};
+  dim3 grid((unsigned)tiles, (unsigned)(g.O1 * g.O2), (unsigned)(conv ? 1 : ksplit)), block(WM * WN * 64);
+  X3Conv cv = {0, 0, 0, 0u, 0u, ksplit, part_stride};
   if (conv) hipLaunchKernelGGL((gemm_nn_x3_kernel<TM, TN, WM, WN, true, true, true>), grid, block, 0, s, g, *conv);
   else if (g.A3 && (g_x3_breg < 0 ? g.N <= 4096 : g_x3_breg != 0) && WM == 1 && TN == 1) {
     if constexpr (WM == 1 && TN == 1) hipLaunchKernelGGL((gemm_nn_x3_kernel<TM, TN, WM, WN, true, true, false, true>), grid, block, 0, s, g, cv);
@@ -390,6 +402,7 @@ extern "C" int pir_split_bf16x3_taps(const float* W, int M, int K, long st, long
   return pir_launch_status();
 }
 
+int g_x3_ksplit = 1;   // knob 45: split of underfilled deep-k products over k (pir_gemm_nn_ws; 0: never)
 int g_x3_conv_split = 1;   // knob 44: split of the underfilled dense 3x3 convolutions over their stages (0: never)
 
 // tile of the dense convolution (rows = output channels, often few)
@@ -450,6 +463,7 @@ static int conv3x3_x3_impl(const void* A3, int a3_kp, const float* X, long x_bs,
   g.M = M; g.K = K; g.N = H * W; g.O1 = B; g.O2 = 1;
   g.A3 = A3; g.a3_kp = a3_kp;
   X3Conv cv;
+  cv.ksplit = 1; cv.part_stride = 0;
   cv.H = H; cv.W = W; cv.ksteps = a3_kp / 16;
   cv.magic_ks = pir_magic((unsigned)cv.ksteps); cv.magic_w = pir_magic((unsigned)W);
   hipStream_t s = (hipStream_t)stream;
@@ -517,6 +531,7 @@ int pir_nn_x3_tune(int knob, int value) {
   if (knob == 43) { g_x3_fill32 = value; return PIR_OK; }
   if (knob == 29) { g_x3_conv_fill = value; return PIR_OK; }
   if (knob == 44) { g_x3_conv_split = value; return PIR_OK; }
+  if (knob == 45) { g_x3_ksplit = value; return PIR_OK; }
   return PIR_EINVAL;
 }
 
@@ -578,15 +593,33 @@ int pir_nn_x3_plan(const pir_gemm_nn_t* a, int cfg) {
   return 2222;
 }
 
-int pir_nn_x3_launch(const pir_gemm_nn_t* a, int cfg, hipStream_t s) {
+
+// Slices the k loop of this product is cut into when a scratch buffer is at hand (1: no split): pre-split weights, one
+// contiguous output per image, fewer workgroups than half of the CUs (the 16^2 level's 384-row products at 1 - 4 images per part:
+// 8 - 32 workgroups walking 64 - 128 k-steps, 28 - 50 us each), at least 16 k-steps per slice.
+int pir_nn_x3_ksplit(const pir_gemm_nn_t* a, int cfg) {
+  const pir_gemm_nn_t& g = *a;
+  if (!g_x3_ksplit || !g.A3 || g.O2 != 1 || g.y_s1 != (long)g.M * g.N || g.ldy != g.N) return 1;
+  const int plan = pir_nn_x3_plan(a, cfg);
+  const int bm = (plan / 1000) * (plan / 10 % 10) * 32, bn = (plan / 100 % 10) * (plan % 10) * 32;
+  const long wgs = pir_cdiv(g.M, bm) * pir_cdiv(g.N, bn) * g.O1;
+  const int iters = (int)pir_cdiv(g.K, 16);
+  if (wgs * 2 >= PIR_NUM_CU) return 1;   // (at 128 workgroups - the 384-row products at 16 images - the split is neutral in the step)
+  long s = 2L * PIR_NUM_CU / wgs;
+  if (s > iters / 16) s = iters / 16;
+  if (s > 8) s = 8;
+  return s < 2 ? 1 : (int)s;
+}
+
+int pir_nn_x3_launch(const pir_gemm_nn_t* a, int cfg, hipStream_t s, int ksplit, long part_stride) {
   const pir_gemm_nn_t& g = *a;
   switch (pir_nn_x3_plan(a, cfg)) {
-    case 1214: return launch_cfg<1, 2, 1, 4>(g, s);
-    case 2214: return launch_cfg<2, 2, 1, 4>(g, s);
-    case 3214: return launch_cfg<3, 2, 1, 4>(g, s);
-    case 2222: return launch_cfg<2, 2, 2, 2>(g, s);
-    case 3114: return launch_cfg<3, 1, 1, 4>(g, s);
-    case 1114: return launch_cfg<1, 1, 1, 4>(g, s);
-    default: return launch_cfg<1, 2, 2, 2>(g, s);
+    case 1214: return launch_cfg<1, 2, 1, 4>(g, s, nullptr, ksplit, part_stride);
+    case 2214: return launch_cfg<2, 2, 1, 4>(g, s, nullptr, ksplit, part_stride);
+    case 3214: return launch_cfg<3, 2, 1, 4>(g, s, nullptr, ksplit, part_stride);
+    case 2222: return launch_cfg<2, 2, 2, 2>(g, s, nullptr, ksplit, part_stride);
+    case 3114: return launch_cfg<3, 1, 1, 4>(g, s, nullptr, ksplit, part_stride);
+    case 1114: return launch_cfg<1, 1, 1, 4>(g, s, nullptr, ksplit, part_stride);
+    default: return launch_cfg<1, 2, 2, 2>(g, s, nullptr, ksplit, part_stride);
   }
 }

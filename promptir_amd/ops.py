@@ -42,7 +42,7 @@ class _TimedLib:
     @staticmethod
     def _bytes(name, args):
         """Algorithmic HBM bytes of one call of the GEMM families (operands read once, result written once)."""
-        if name == "pir_gemm_nn":
+        if name in ("pir_gemm_nn", "pir_gemm_nn_ws"):
             g = args[0]._obj
             o = g.O1 * g.O2
             shared = g.a_s1 == 0 and g.a_s2 == 0
@@ -91,7 +91,7 @@ class _TimedLib:
     @staticmethod
     def _work(name, args):
         """Algorithmic FLOPs of one call for the MFMA families (0 for the streaming kernels)."""
-        if name == "pir_gemm_nn":
+        if name in ("pir_gemm_nn", "pir_gemm_nn_ws"):
             g = args[0]._obj
             return 2.0 * g.M * g.K * g.N * g.O1 * g.O2
         if name in ("pir_gemm_nt", "pir_gemm_nt_partials"):
@@ -133,7 +133,8 @@ class _TimedLib:
             status = fn(*args)
             end.record()
             if status != 1000:      # 1000 = shape not served, nothing launched (the caller runs the unfused pair)
-                label = name + "@" + _TAG[-1] if _TAG else name
+                base = {"pir_gemm_nn_ws": "pir_gemm_nn", "pir_conv3x3_x3_ws": "pir_conv3x3_x3"}.get(name, name)   # same op, with scratch
+                label = base + "@" + _TAG[-1] if _TAG else base
                 self.records.append((label, start, end, self._work(name, args), self._bytes(name, args)))
             return status
 
@@ -450,6 +451,11 @@ def gemm_nn(A: torch.Tensor, a_batch: Tuple[int, int], a_sm: int, a_sk: int,
     if rowscale is not None:
         g.rowscale, g.rs_s1, g.rs_s2 = rowscale.data_ptr(), rs_batch[0], rs_batch[1]
     g.M, g.K, g.N, g.O1, g.O2 = M, K, N, O1, O2
+    need = lib.pir_gemm_nn_ws_floats(C.byref(g)) if A3 is not None else 0
+    if need:      # an underfilled deep-k product: split over k, partial sums in a scratch slot of their own
+        ws = workspace(need, X.device, slot="gemm_nn")
+        check(lib.pir_gemm_nn_ws(C.byref(g), ws.data_ptr(), ws.numel(), _stream()), "pir_gemm_nn_ws")
+        return
     check(lib.pir_gemm_nn(C.byref(g), _stream()), "pir_gemm_nn")
 
 

@@ -130,6 +130,39 @@ def test_weight_gradient_with_the_tall_operand_private_to_its_wave(b, cin, cout,
     assert torch.equal(got, again)
 
 
+@pytest.mark.parametrize("b,cin,cout,h,w", [(7, 2042, 384, 16, 16), (4, 1021, 384, 16, 16), (1, 1152, 384, 16, 16), (2, 510, 192, 32, 32),
+                                            (1, 2042, 384, 16, 16), (3, 300, 100, 8, 8), (16, 384, 2042, 16, 16)])
+def test_deep_k_products_of_underfilled_launches_split_over_k(b, cin, cout, h, w):
+    """gemm.hip / gemm_x3.hip, knob 45 (pir_gemm_nn_ws): a 1x1 convolution whose launch leaves most CUs idle behind a long k
+    loop is cut into slices of its k-steps; the partial sums (the residual in slice 0) are added in order by the second
+    stage.  Forward, forward + residual and input gradient vs F.conv2d on the CPU and vs the unsplit launch (fp32
+    rounding), bit-stable across launches; the last shape (k = 384) and batch-16 wide outputs are not split."""
+    from promptir_amd import _lib, ops
+
+    L = _lib.lib
+    x, wt, res = rnd("x", b, cin, h, w), rnd("w", cout, cin, 1, 1) * 0.05, rnd("r", b, cout, h, w)
+    dy = rnd("dy", b, cout, h, w)
+    xr = x.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wt)
+    ref.backward(dy)
+    xd, wd_, rd, dyd = x.to(DEV), wt.to(DEV), res.to(DEV), dy.to(DEV)
+    outs = []
+    try:
+        for mode in (0, 1, 1):
+            assert L.pir_tune_set(45, mode) == 0
+            outs.append([ops.conv1x1_forward(xd, wd_).clone(), ops.conv1x1_forward(xd, wd_, residual=rd).clone(),
+                         ops.conv1x1_dgrad(dyd, wd_).clone()])
+    finally:
+        L.pir_tune_set(45, 1)
+    for a, bb in zip(outs[1], outs[2]):
+        assert torch.equal(a, bb)
+    close(outs[1][0], ref.detach(), rtol=3e-5)
+    close(outs[1][1], ref.detach() + res, rtol=3e-5)
+    close(outs[1][2], xr.grad, rtol=3e-5)
+    for a, bb in zip(outs[0], outs[1]):
+        close(a, bb.cpu(), rtol=1e-5)
+
+
 @pytest.mark.parametrize("b,cin,cout,h,w", [(4, 384, 768, 16, 16), (1, 192, 384, 32, 32), (4, 320, 320, 16, 16), (2, 192, 96, 32, 32),
                                             (1, 100, 70, 16, 32), (3, 64, 64, 64, 64)])
 def test_dense_convolutions_split_over_their_stages(b, cin, cout, h, w):
@@ -178,12 +211,14 @@ def test_narrow_tiles_of_underfilled_launches_change_no_bit(b, cin, cout, h, w):
     dy = rnd("dy", b, cout, h, w).to(DEV)
     outs = []
     try:
+        assert L.pir_tune_set(45, 0) == 0      # (the split over k follows the workgroup count: another grouping of the sum)
         for mode in (0, 45, 100):
             assert L.pir_tune_set(43, mode) == 0
             outs.append([ops.conv1x1_forward(x, wt).clone(), ops.conv1x1_forward(x, wt, residual=res).clone(),
                          ops.conv1x1_dgrad(dy, wt).clone()])
     finally:
         L.pir_tune_set(43, 45)
+        L.pir_tune_set(45, 1)
     for other in outs[1:]:
         for a, bb in zip(outs[0], other):
             assert torch.equal(a, bb)
