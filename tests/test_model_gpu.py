@@ -233,6 +233,12 @@ def test_concat_producers_write_in_place():
     deg, clean = W.synthetic_pair(2, 64, 64, sigma=[25, 50], seed=31)
     x, t = torch.from_numpy(deg).to(dev), torch.from_numpy(clean).to(dev)
     res = {}
+    from promptir_amd import _lib
+
+    # the splits of underfilled launches (knobs 44, 45) need a contiguous output: a producer that writes into its half of a
+    # concat buffer is not split, the copying form is - another grouping of the same sums, so they are off for the bit test
+    _lib.lib.pir_tune_set(44, 0)
+    _lib.lib.pir_tune_set(45, 0)
     for inplace in (False, True):
         ops.CAT_INPLACE = inplace
         try:
@@ -266,3 +272,6 @@ def test_concat_producers_write_in_place():
     net, _ = _net(ctor, 17, dev)
     with torch.no_grad():
         assert torch.equal(net(x), res[True][0])
+
+    _lib.lib.pir_tune_set(44, 1)
+    _lib.lib.pir_tune_set(45, 1)
